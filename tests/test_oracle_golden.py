@@ -1,0 +1,66 @@
+"""Pin the oracle: the CPU restatement must reproduce every stage boundary the real reference
+produced for the golden cases (tests/golden/make_golden.py generated them from /root/reference)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.vispeech_oracle import Oracle, rq_spline
+from vispeech_amd.schema import ModelDims
+from vispeech_amd.synth import synth_state_dict
+
+CASES = ["ragged_controls", "ragged_predictors", "maxlen_dur3d", "c1_filelist"]
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    dims = ModelDims()
+    return Oracle(synth_state_dict(dims, seed=1234, infer_only=True), dims)
+
+
+def run_oracle_on_case(oracle, g):
+    use = g["in_use"]
+    sc = g["in_scalar"]
+    max_len = int(g["in_max_len"])
+    return oracle.infer(
+        g["in_phonemes"], g["in_lengths"], g["in_sid"], noise=g["in_noise"],
+        noise_scale=float(g["in_noise_scale"]), max_len=None if max_len < 0 else max_len,
+        duration_control=g["in_duration"] if use[0] else float(sc[0]),
+        pitch_control=g["in_f0"] if use[1] else float(sc[1]),
+        energy_control=g["in_energy"] if use[2] else float(sc[2]))
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_matches_reference_outputs(oracle, golden_dir, case):
+    g = np.load(os.path.join(golden_dir, f"{case}.npz"))
+    out = run_oracle_on_case(oracle, g)
+    # integer-valued / boolean outputs are exact
+    np.testing.assert_array_equal(out["duration"].reshape(g["duration"].shape).numpy(), g["duration"])
+    np.testing.assert_array_equal(out["x_mask"].numpy(), g["x_mask"])
+    assert out["x_mask"].dtype == torch.bool
+    # floating-point stage boundaries: <= 1e-5 relative to the tensor's max
+    for name in ["x_enc", "x_frame", "h_frame", "m_p", "logs_p", "z_p", "z", "F0", "energy"]:
+        e = rel_err(out[name].numpy(), g[name])
+        assert e <= 1e-5, (case, name, e)
+    # waveform: <= 1e-4 * max|ref|
+    assert out["o"].shape == g["o"].shape
+    assert rel_err(out["o"].numpy(), g["o"]) <= 1e-4, case
+
+
+def test_spline_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "spline.npz"))
+    for inv, yk, lk in ((False, "y_fwd", "lad_fwd"), (True, "y_inv", "lad_inv")):
+        y, lad = rq_spline(g["x"], g["uw"], g["uh"], g["ud"], inverse=inv, tail_bound=5.0)
+        assert np.abs(y.numpy() - g[yk]).max() <= 1e-5
+        assert np.abs(lad.numpy() - g[lk]).max() <= 1e-4
+    # round trip
+    y, _ = rq_spline(g["x"], g["uw"], g["uh"], g["ud"], inverse=False)
+    x2, _ = rq_spline(y, g["uw"], g["uh"], g["ud"], inverse=True)
+    assert np.abs(x2.numpy() - g["x"]).max() <= 1e-3   # fp32 round trip (SURVEY: 3.6e-5 typical)
