@@ -1,0 +1,175 @@
+/*
+ * vispeech_hip.h -- C-ABI of the MI355X (gfx950) synthesis path.
+ *
+ * The reference (innnky/vispeech) has NO native/FFI layer: the only boundary its hot path sits
+ * behind is the Python method SynthesizerTrn.infer (reference models.py:672-722) and the
+ * checkpoint key schema (reference utils.py:21-51, 67-70).  This header is the C boundary a
+ * maintainer binds that method to (ctypes stub in INTEGRATION.md; vispeech_amd/models.py is the
+ * shipped binding).  Conventions:
+ *   - every entry point returns int: 0 = ok, negative = error class (VSP_ERR_*); nothing throws;
+ *     vsp_last_error() gives the message of the last failure on that context.
+ *   - plain pointers and sizes only.  "dev" pointers are HIP device pointers owned by the CALLER
+ *     (torch tensors' data_ptr()); the library owns only its packed weight arena (unless the
+ *     caller supplies one) -- no hidden allocation happens on the infer path.
+ *   - all work is enqueued on the caller's stream (void* = hipStream_t); the only host
+ *     synchronisation is in vsp_frame_lengths_host (the read of the frame counts, which replaces
+ *     the B*T_p .item() syncs of reference models.py:398-427).
+ *   - activations are float32, laid out [B][C][T] with T contiguous, exactly like the reference's
+ *     tensors; a tensor argument is (ptr, batch_stride, channel_stride) in ELEMENTS.
+ *   - one context per device; a context is not thread-safe (the reference serialises infer calls
+ *     with a lock, inference_api.py:13,37); different contexts are independent.
+ */
+#ifndef VISPEECH_HIP_H
+#define VISPEECH_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSP_ABI_VERSION 1
+
+enum {
+  VSP_OK = 0,
+  VSP_ERR_ARG = -1,        /* null / out-of-range argument */
+  VSP_ERR_STATE = -2,      /* call order (weights not finalised, ...) */
+  VSP_ERR_HIP = -3,        /* a HIP runtime call failed */
+  VSP_ERR_KEY = -4,        /* unknown state_dict key */
+  VSP_ERR_SHAPE = -5,      /* tensor shape differs from the schema */
+  VSP_ERR_WORKSPACE = -6,  /* workspace too small */
+  VSP_ERR_UNSUPPORTED = -7 /* configuration outside what the kernels cover */
+};
+
+#define VSP_MAX_LIST 8
+
+/* Hyper-parameters that fix tensor shapes: the constructor arguments of the reference's
+ * SynthesizerTrn (models.py:537-561) plus the constants its code hard-wires
+ * (attentions.py:14 window 4; models.py:498 6 pitch layers; :599 duration filter 256;
+ * frame_prior_network.py:65 energy filter 768; models.py:597 WN kernel 5 / 4 layers; :184 4 flows). */
+typedef struct vsp_config {
+  int32_t n_vocab;
+  int32_t inter_channels;
+  int32_t hidden_channels;
+  int32_t filter_channels;
+  int32_t n_heads;
+  int32_t n_layers;
+  int32_t kernel_size;
+  int32_t n_resblock_kernels;
+  int32_t resblock_kernel_sizes[VSP_MAX_LIST];
+  int32_t n_resblock_dilations;                       /* dilations per ResBlock1 (3) */
+  int32_t resblock_dilation_sizes[VSP_MAX_LIST][VSP_MAX_LIST];
+  int32_t n_upsamples;
+  int32_t upsample_rates[VSP_MAX_LIST];
+  int32_t upsample_kernel_sizes[VSP_MAX_LIST];
+  int32_t upsample_initial_channel;
+  int32_t n_speakers;
+  int32_t gin_channels;
+  int32_t window_size;
+  int32_t pitch_layers;
+  int32_t dur_filter;
+  int32_t energy_filter;
+  int32_t flow_kernel;
+  int32_t flow_layers;
+  int32_t n_flows;
+} vsp_config;
+
+typedef struct vsp_ctx vsp_ctx;
+
+/* ---- lifetime --------------------------------------------------------------------------- */
+int vsp_abi_version(void);
+/* Replaces SynthesizerTrn.__init__ (reference models.py:537-622) for the infer path. */
+int vsp_create(const vsp_config* cfg, int device, vsp_ctx** out);
+int vsp_destroy(vsp_ctx* ctx);
+const char* vsp_last_error(const vsp_ctx* ctx);
+
+/* ---- weights: replaces load_state_dict / utils.load_checkpoint (reference utils.py:21-51) - */
+/* One call per state_dict tensor, raw reference keys ("dec.ups.0.weight_v", ...), float32 HOST
+ * data (copied).  weight_g/weight_v pairs are folded by vsp_finalize_weights exactly as
+ * torch.nn.utils.weight_norm does (reference modules.py:128,135,145,191-206; models.py:255: for
+ * ConvTranspose1d the norm is per INPUT channel).  Keys that infer never reads (enc_q.*,
+ * enc_p.proj.*, frame_prior_net.emb.*, energy_predictor.predictor.proj.*) are accepted and
+ * ignored; unknown keys return VSP_ERR_KEY. */
+int vsp_set_weight(vsp_ctx* ctx, const char* key, const float* host_data, const int64_t* shape, int ndim);
+/* Number of infer-path tensors still missing (0 = ready to finalise). */
+int vsp_missing_weights(const vsp_ctx* ctx);
+/* Size of the packed device arena (depends on the config only). */
+int64_t vsp_weight_arena_bytes(const vsp_ctx* ctx);
+/* Fold + pack (MFMA fragment order) + upload.  dev_arena may be NULL (the library allocates). */
+int vsp_finalize_weights(vsp_ctx* ctx, void* dev_arena);
+/* Multi-GPU: a non-root rank adopts an arena that already holds rank 0's packed bytes
+ * (received by an RCCL broadcast); no host weights needed. */
+int vsp_adopt_packed_weights(vsp_ctx* ctx, void* dev_arena);
+/* The arena this context reads its weights from (for the broadcast on rank 0). */
+int vsp_weight_arena(const vsp_ctx* ctx, void** dev_arena, int64_t* bytes);
+
+/* ---- the path: replaces SynthesizerTrn.infer (reference models.py:672-722) ---------------- */
+/* Phoneme-rate half, models.py:674-708 + the prefix sum of LengthRegulator (models.py:398-427):
+ *   speaker embedding, TextEncoder, duration / F0 / energy (predicted, or the *_ctl tensor when
+ *   non-NULL -- the reference's isinstance(.., torch.Tensor) branches), pitch/energy prenets.
+ * Inputs (device): phonemes[B*Tp] int64, lengths[B] int64, sid[B] int64; *_ctl [B*Tp] float or NULL
+ *   with the scalar controls used instead (reference defaults 1.0).
+ * Outputs (device): x_var [B][H][Tp] (text encoding + prenets, the length regulator's input),
+ *   g [B][gin], duration/f0/energy [B*Tp], frame_lengths[B] int64, cum_dur [B*Tp] int32.
+ * workspace: >= vsp_encode_workspace_bytes(ctx,B,Tp). */
+int64_t vsp_encode_workspace_bytes(const vsp_ctx* ctx, int B, int Tp);
+int vsp_encode(vsp_ctx* ctx, void* stream, int B, int Tp,
+               const int64_t* phonemes, const int64_t* lengths, const int64_t* sid,
+               const float* duration_ctl, const float* pitch_ctl, const float* energy_ctl,
+               float duration_scale, float pitch_scale, float energy_scale,
+               float* x_var, float* g, float* duration, float* f0, float* energy,
+               int64_t* frame_lengths, int32_t* cum_dur,
+               void* workspace, int64_t workspace_bytes);
+/* Copies frame_lengths[B] to the host (one stream sync) and returns max(frame_lengths). */
+int vsp_frame_lengths_host(vsp_ctx* ctx, void* stream, int B, const int64_t* frame_lengths_dev,
+                           int64_t* frame_lengths_host, int64_t* max_frames);
+
+/* Frame-rate half, models.py:711-720: length-regulator expand, FramePriorNet, Projection +
+ * reparameterisation with the caller's noise (models.py:718), inverse flow, HiFi-GAN generator.
+ * Tf = padded frame count of the batch (>= every frame length; the GLOBAL maximum in a sharded
+ * run, SURVEY gotcha G6).  max_len < 0 = no truncation; the generator consumes
+ * Tdec = min(Tf, max_len) frames and writes o[B][1][Tdec * prod(upsample_rates)].
+ * noise [B][inter][Tf] (ignored if noise_scale == 0 and NULL).
+ * Outputs (device, contiguous): o, x_mask[B*Tf] uint8, z, z_p, m_p, logs_p [B][inter][Tf]. */
+int64_t vsp_decode_workspace_bytes(const vsp_ctx* ctx, int B, int Tp, int Tf);
+int vsp_decode(vsp_ctx* ctx, void* stream, int B, int Tp, int Tf, int max_len,
+               const float* x_var, const float* g, const int32_t* cum_dur, const int64_t* frame_lengths,
+               const float* noise, float noise_scale,
+               float* o, uint8_t* x_mask, float* z, float* z_p, float* m_p, float* logs_p,
+               void* workspace, int64_t workspace_bytes);
+
+/* ---- per-stage entry points (unit parity against the oracle) ------------------------------ */
+/* attentions.Encoder.forward (reference attentions.py:35-47). which: 0 = enc_p.encoder,
+ * 1 = pitch_predictor.pitch_net, 2 = frame_prior_net.fft_block.  x [B][H][T] in, y [B][H][T] out. */
+int64_t vsp_encoder_workspace_bytes(const vsp_ctx* ctx, int B, int T);
+int vsp_encoder(vsp_ctx* ctx, void* stream, int which, int B, int T, const float* x,
+                const int64_t* lengths, float* y, void* workspace, int64_t workspace_bytes);
+/* LengthRegulator (reference models.py:398-427) from a ready prefix sum. */
+int vsp_length_regulate(vsp_ctx* ctx, void* stream, int B, int C, int Tp, int Tf, const float* x,
+                        const int32_t* cum_dur, float* x_frame);
+/* ResidualCouplingBlock.forward(reverse=True) (reference models.py:202-209). z_p -> z, in place
+ * semantics on a copy: z is written, z_p is read. */
+int64_t vsp_flow_workspace_bytes(const vsp_ctx* ctx, int B, int Tf);
+int vsp_flow_reverse(vsp_ctx* ctx, void* stream, int B, int Tf, const float* z_p, const float* g,
+                     const int64_t* frame_lengths, float* z, void* workspace, int64_t workspace_bytes);
+/* Generator.forward (reference models.py:271-290). z [B][inter][T] (already masked/truncated). */
+int64_t vsp_generator_workspace_bytes(const vsp_ctx* ctx, int B, int T);
+int vsp_generator(vsp_ctx* ctx, void* stream, int B, int T, const float* z, const float* g,
+                  float* o, void* workspace, int64_t workspace_bytes);
+/* piecewise_rational_quadratic_transform with tails='linear' (reference transforms.py:12-193),
+ * n elements, nb bins; uw/uh [n][nb], ud [n][nb-1]; outputs y[n], logabsdet[n]. */
+int vsp_rq_spline(void* stream, int64_t n, int nb, const float* x, const float* uw, const float* uh,
+                  const float* ud, int inverse, float tail_bound, float* y, float* logabsdet);
+
+/* ---- measurement -------------------------------------------------------------------------- */
+/* When enabled, every launch of the dominant kernel (the MFMA implicit-GEMM conv) inside the
+ * generator is bracketed by a HIP event pair on the launch stream.  vsp_profile_read synchronises
+ * those events and returns, since the last reset: the number of launches, their summed duration
+ * in milliseconds, and their summed algorithmic FLOPs (2 * rows * Cin * taps * columns * B). */
+int vsp_profile_enable(vsp_ctx* ctx, int on);
+int vsp_profile_read(vsp_ctx* ctx, int64_t* launches, double* total_ms, double* total_flops, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VISPEECH_HIP_H */

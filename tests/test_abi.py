@@ -1,0 +1,122 @@
+"""CPU-only checks of the C-ABI library: it loads, exports every symbol include/vispeech_hip.h
+declares, and its host logic (schema validation, arena planning, workspace sizing) behaves.
+No kernel is launched here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from vispeech_amd import _lib
+from vispeech_amd.schema import ModelDims, infer_schema, state_dict_schema, used_by_infer
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "vispeech_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vsp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.lib()
+    syms = header_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(lib, s), s
+    assert sorted(_lib.SIGNATURES) == syms, "ctypes signature table and header disagree"
+    assert lib.vsp_abi_version() == 1
+
+
+@pytest.fixture()
+def ctx():
+    lib = _lib.lib()
+    cfg = _lib.make_config(ModelDims())
+    h = C.c_void_p()
+    assert lib.vsp_create(C.byref(cfg), 0, C.byref(h)) == 0
+    yield lib, h
+    lib.vsp_destroy(h)
+
+
+def _set(lib, h, key, arr):
+    a = np.ascontiguousarray(arr, dtype=np.float32)
+    shape = (C.c_int64 * max(a.ndim, 1))(*a.shape)
+    return lib.vsp_set_weight(h, key.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim)
+
+
+def test_schema_matches_python_schema(ctx):
+    lib, h = ctx
+    dims = ModelDims()
+    schema = state_dict_schema(dims)
+    n_used = sum(1 for k in schema if used_by_infer(k))
+    assert lib.vsp_missing_weights(h) == n_used
+    for k, shape in schema.items():
+        assert _set(lib, h, k, np.zeros(shape, dtype=np.float32)) == 0, (k, lib.vsp_last_error(h))
+    assert lib.vsp_missing_weights(h) == 0
+    assert len(schema) == 753            # the reference's state_dict size
+
+
+def test_bad_key_and_shape_are_rejected(ctx):
+    lib, h = ctx
+    assert _set(lib, h, "dec.nonexistent.weight", np.zeros((1,))) == -4
+    assert b"unknown" in lib.vsp_last_error(h)
+    assert _set(lib, h, "dec.conv_pre.bias", np.zeros((7,))) == -5
+    # pre-folded weight accepted where the schema has weight_v
+    assert _set(lib, h, "dec.ups.0.weight", np.zeros((512, 256, 16))) == 0
+
+
+def test_arena_and_workspace_sizes(ctx):
+    lib, h = ctx
+    arena = lib.vsp_weight_arena_bytes(h)
+    n_params = sum(int(np.prod(s)) for s in infer_schema(ModelDims()).values())
+    # packed arena holds every infer-path parameter (weight_g folded away, some zero padding)
+    assert 0.9 * 4 * n_params < arena < 1.3 * 4 * n_params
+    e1, e2 = lib.vsp_encode_workspace_bytes(h, 2, 40), lib.vsp_encode_workspace_bytes(h, 4, 40)
+    assert 0 < e1 < e2
+    d1, d2 = lib.vsp_decode_workspace_bytes(h, 1, 40, 100), lib.vsp_decode_workspace_bytes(h, 1, 40, 200)
+    assert 0 < d1 < d2
+    # generator dominates: 5 buffers of B * max_stage(C*T) floats
+    g = lib.vsp_generator_workspace_bytes(h, 1, 100)
+    assert g >= 5 * 4 * 32 * 100 * 512
+    assert lib.vsp_decode_workspace_bytes(h, 0, 40, 100) < 0
+
+
+def test_calls_before_finalize_fail_loudly(ctx):
+    lib, h = ctx
+    rc = lib.vsp_generator(h, None, 1, 8, C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), 1 << 20)
+    assert rc == -2 and b"not finalised" in lib.vsp_last_error(h)
+    assert lib.vsp_finalize_weights(h, None) == -2      # weights missing
+
+
+def test_unsupported_configs_are_reported():
+    lib = _lib.lib()
+    d = ModelDims()
+    d.n_heads = 3            # head dim 64 is covered; 192/3 = 64 -> ok; use 4 -> 48 unsupported
+    d.n_heads = 4
+    cfg = _lib.make_config(d)
+    h = C.c_void_p()
+    assert lib.vsp_create(C.byref(cfg), 0, C.byref(h)) == -7
+    assert b"head dim" in lib.vsp_last_error(h)
+    lib.vsp_destroy(h)
+    d = ModelDims()
+    d.n_speakers = 0
+    cfg = _lib.make_config(d)
+    assert lib.vsp_create(C.byref(cfg), 0, C.byref(h)) == -7
+    lib.vsp_destroy(h)
+
+
+def test_missing_extension_is_an_import_error(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError):
+        _lib.lib()
+
+
+def test_model_refuses_cpu_device():
+    from vispeech_amd import config as vcfg
+    from vispeech_amd.models import SynthesizerTrn
+    args, kwargs = vcfg.synthesizer_args(vcfg.default_hparams())
+    with pytest.raises(RuntimeError):
+        SynthesizerTrn(*args, device="cpu", **kwargs)

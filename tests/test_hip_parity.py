@@ -1,0 +1,243 @@
+"""Parity of the HIP path (through the C-ABI) against the golden vectors produced by the real
+reference and against the CPU oracle on seeded inputs.  Needs an MI355X: `pytest -m gpu`.
+
+Tolerances: integer-valued outputs exact; floating-point stage boundaries
+<= STAGE_TOL * max|ref| ; waveform <= WAVE_TOL * max|ref|.  The kernels compute in f32 on the
+matrix core (v_mfma_f32_32x32x2_f32 = exact fmaf chain), so the only difference from the
+reference's fp32 CPU path is summation order.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+STAGE_TOL = 2e-5
+WAVE_TOL = 1e-4
+
+CASES = ["ragged_controls", "ragged_predictors", "maxlen_dur3d", "c1_filelist"]
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def to_np(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def dims():
+    from vispeech_amd.schema import ModelDims
+    return ModelDims()
+
+
+@pytest.fixture(scope="module")
+def weights(dims):
+    from vispeech_amd.synth import synth_state_dict
+    return synth_state_dict(dims, seed=1234, infer_only=True)
+
+
+@pytest.fixture(scope="module")
+def net(dims, weights):
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    from vispeech_amd import config as vcfg
+    from vispeech_amd.models import SynthesizerTrn
+    args, kwargs = vcfg.synthesizer_args(vcfg.default_hparams())
+    m = SynthesizerTrn(*args, **kwargs).eval()
+    m.load_state_dict(weights, strict=True)
+    return m
+
+
+@pytest.fixture(scope="module")
+def oracle(dims, weights):
+    from oracle.vispeech_oracle import Oracle
+    return Oracle(weights, dims)
+
+
+def golden(golden_dir, case):
+    return np.load(os.path.join(golden_dir, f"{case}.npz"))
+
+
+def run_case(net, g):
+    use, sc = g["in_use"], g["in_scalar"]
+    max_len = int(g["in_max_len"])
+    dev = net.device
+    t = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
+    return net.infer(
+        t(g["in_phonemes"]), t(g["in_lengths"]), sid=t(g["in_sid"]), noise_scale=float(g["in_noise_scale"]),
+        max_len=None if max_len < 0 else max_len,
+        duration_control=t(g["in_duration"]) if use[0] else float(sc[0]),
+        pitch_control=t(g["in_f0"]) if use[1] else float(sc[1]),
+        energy_control=t(g["in_energy"]) if use[2] else float(sc[2]),
+        noise=t(g["in_noise"]))
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_infer_matches_reference_golden(net, golden_dir, case):
+    """Full SynthesizerTrn.infer through the shim vs the outputs of the real reference."""
+    g = golden(golden_dir, case)
+    o, x_mask, (z, z_p, m_p, logs_p), duration, f0, energy = run_case(net, g)
+    assert x_mask.dtype == torch.bool
+    np.testing.assert_array_equal(to_np(x_mask), g["x_mask"])
+    np.testing.assert_array_equal(to_np(duration).reshape(g["duration"].shape), g["duration"])
+    errs = {}
+    for name, val in (("m_p", m_p), ("logs_p", logs_p), ("z_p", z_p), ("z", z), ("F0", f0), ("energy", energy)):
+        errs[name] = rel_err(to_np(val), g[name])
+    errs["o"] = rel_err(to_np(o), g["o"])
+    print(case, {k: f"{v:.2e}" for k, v in errs.items()})
+    for name in ("m_p", "logs_p", "z_p", "z", "F0", "energy"):
+        assert errs[name] <= STAGE_TOL, (case, name, errs[name])
+    assert errs["o"] <= WAVE_TOL, (case, errs["o"])
+
+
+@pytest.mark.parametrize("case", ["ragged_controls", "c1_filelist"])
+def test_stage_text_encoder(net, weights, dims, golden_dir, case):
+    g = golden(golden_dir, case)
+    emb = weights["enc_p.symbol_emb.weight"][g["in_phonemes"]] * np.float32(math.sqrt(dims.hidden_channels))
+    x = np.ascontiguousarray(np.transpose(emb, (0, 2, 1)))
+    y = net._engine.encoder(0, x, g["in_lengths"])
+    e = rel_err(to_np(y), g["x_enc"])
+    print("x_enc", case, f"{e:.2e}")
+    assert e <= STAGE_TOL
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_stage_length_regulator_exact(net, oracle, golden_dir, case):
+    """The expand is a pure gather: bit-exact against the reference's x_frame when fed the
+    oracle's (reference-pinned) phoneme-rate tensor."""
+    g = golden(golden_dir, case)
+    use, sc = g["in_use"], g["in_scalar"]
+    enc = oracle.encode(g["in_phonemes"], g["in_lengths"], g["in_sid"],
+                        g["in_duration"] if use[0] else float(sc[0]), g["in_f0"] if use[1] else float(sc[1]),
+                        g["in_energy"] if use[2] else float(sc[2]))
+    d = enc["duration"].reshape(g["in_phonemes"].shape).numpy()
+    cum = np.cumsum(np.maximum(np.trunc(d), 0).astype(np.int64), axis=1).astype(np.int32)
+    tf = g["x_frame"].shape[2]
+    y = net._engine.length_regulate(enc["x_var"], cum, tf)
+    np.testing.assert_array_equal(to_np(y), enc["x_frame"].numpy())
+    assert rel_err(to_np(y), g["x_frame"]) <= 1e-5
+
+
+@pytest.mark.parametrize("case", ["ragged_controls", "ragged_predictors"])
+def test_stage_frame_prior(net, golden_dir, case):
+    g = golden(golden_dir, case)
+    lens = g["x_mask"][:, 0, :].sum(axis=1).astype(np.int64)
+    y = net._engine.encoder(2, g["x_frame"], lens)
+    e = rel_err(to_np(y), g["h_frame"])
+    print("h_frame", case, f"{e:.2e}")
+    assert e <= STAGE_TOL
+
+
+@pytest.mark.parametrize("case", ["ragged_controls", "c1_filelist"])
+def test_stage_flow(net, weights, golden_dir, case):
+    g = golden(golden_dir, case)
+    lens = g["x_mask"][:, 0, :].sum(axis=1).astype(np.int64)
+    gvec = weights["emb_g.weight"][g["in_sid"]]
+    z = net._engine.flow_reverse(g["z_p"], gvec, lens)
+    e = rel_err(to_np(z), g["z"])
+    print("flow", case, f"{e:.2e}")
+    assert e <= STAGE_TOL
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_stage_generator(net, weights, golden_dir, case):
+    g = golden(golden_dir, case)
+    max_len = int(g["in_max_len"])
+    zin = g["z"] * g["x_mask"].astype(np.float32)
+    if max_len >= 0:
+        zin = zin[:, :, :max_len]
+    gvec = weights["emb_g.weight"][g["in_sid"]]
+    o = net._engine.generator(np.ascontiguousarray(zin), gvec)
+    e = rel_err(to_np(o), g["o"])
+    print("generator", case, f"{e:.2e}")
+    assert e <= WAVE_TOL
+
+
+def test_spline_matches_reference_golden(golden_dir):
+    from vispeech_amd.engine import rq_spline
+    g = np.load(os.path.join(golden_dir, "spline.npz"))
+    for inv, yk, lk in ((False, "y_fwd", "lad_fwd"), (True, "y_inv", "lad_inv")):
+        y, lad = rq_spline(g["x"], g["uw"], g["uh"], g["ud"], inverse=inv, tail_bound=5.0)
+        ey = np.abs(to_np(y) - g[yk]).max()
+        el = np.abs(to_np(lad) - g[lk]).max()
+        print("spline", inv, f"{ey:.2e} {el:.2e}")
+        assert ey <= 1e-4 and el <= 1e-4
+    y, _ = rq_spline(g["x"], g["uw"], g["uh"], g["ud"], inverse=False)
+    x2, _ = rq_spline(y, g["uw"], g["uh"], g["ud"], inverse=True)
+    assert np.abs(to_np(x2) - g["x"]).max() <= 1e-3
+
+
+def _oracle_vs_hip(net, oracle, batch, **kw):
+    dev = net.device
+    t = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
+    ref = oracle.infer(batch["phonemes"], batch["lengths"], batch["sid"], noise=batch["noise"], noise_scale=0.667,
+                       duration_control=batch["duration"], pitch_control=batch["f0"], energy_control=batch["energy"], **kw)
+    o, x_mask, (z, z_p, m_p, logs_p), duration, f0, energy = net.infer(
+        t(batch["phonemes"]), t(batch["lengths"]), sid=t(batch["sid"]), noise_scale=0.667,
+        duration_control=t(batch["duration"]), pitch_control=t(batch["f0"]), energy_control=t(batch["energy"]),
+        noise=t(batch["noise"]), **kw)
+    return ref, dict(o=o, x_mask=x_mask, z=z, z_p=z_p, m_p=m_p, logs_p=logs_p)
+
+
+def test_oracle_parity_medium_batch(net, oracle):
+    """Seeded ragged batch larger than the golden cases (multi-tile in every kernel: T_f > 128,
+    generator rows > 1024 columns) against the CPU oracle."""
+    from vispeech_amd.synth import synth_batch
+    batch = synth_batch(3, seed=21, mean_phonemes=24, std_phonemes=6, min_phonemes=12, max_phonemes=40,
+                        mean_frames=150, jitter_frames=30)
+    ref, out = _oracle_vs_hip(net, oracle, batch)
+    np.testing.assert_array_equal(to_np(out["x_mask"]), ref["x_mask"].numpy())
+    for name in ("m_p", "logs_p", "z_p", "z"):
+        e = rel_err(to_np(out[name]), ref[name].numpy())
+        print(name, f"{e:.2e}")
+        assert e <= STAGE_TOL, (name, e)
+    e = rel_err(to_np(out["o"]), ref["o"].numpy())
+    print("o", f"{e:.2e}")
+    assert e <= WAVE_TOL
+
+
+def test_sharded_batch_equals_unsharded(net):
+    """SURVEY gotcha G6: with every shard padded to the global T_f, per-utterance results do not
+    depend on which shard they ran in (bit-exact: same kernels, same tiles per utterance)."""
+    from vispeech_amd.synth import synth_batch
+    batch = synth_batch(4, seed=33, mean_phonemes=16, std_phonemes=4, min_phonemes=8, max_phonemes=24,
+                        mean_frames=70, jitter_frames=20)
+    dev = net.device
+    t = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
+    tf = int(batch["frame_lengths"].max())
+
+    def run(sl):
+        return net.infer(t(batch["phonemes"][sl]), t(batch["lengths"][sl]), sid=t(batch["sid"][sl]), noise_scale=0.667,
+                         duration_control=t(batch["duration"][sl]), pitch_control=t(batch["f0"][sl]),
+                         energy_control=t(batch["energy"][sl]), noise=t(batch["noise"][sl]), t_f=tf)
+    full = run(slice(0, 4))
+    a, b = run(slice(0, 2)), run(slice(2, 4))
+    np.testing.assert_array_equal(to_np(full[0]), np.concatenate([to_np(a[0]), to_np(b[0])], axis=0))
+    np.testing.assert_array_equal(to_np(full[2][0]), np.concatenate([to_np(a[2][0]), to_np(b[2][0])], axis=0))
+
+
+def test_valid_region_properties(net):
+    """Size-independent properties: outputs finite and within tanh range; frames beyond each
+    utterance's length are zero in z; m_p/logs_p masked."""
+    from vispeech_amd.synth import synth_batch
+    batch = synth_batch(2, seed=44, mean_phonemes=20, std_phonemes=4, min_phonemes=10, max_phonemes=30,
+                        mean_frames=200, jitter_frames=40)
+    dev = net.device
+    t = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
+    o, x_mask, (z, z_p, m_p, logs_p), *_ = net.infer(
+        t(batch["phonemes"]), t(batch["lengths"]), sid=t(batch["sid"]), noise_scale=0.667,
+        duration_control=t(batch["duration"]), pitch_control=t(batch["f0"]), energy_control=t(batch["energy"]),
+        noise=t(batch["noise"]))
+    assert torch.isfinite(o).all() and o.abs().max() <= 1.0
+    m = x_mask.to(torch.float32)
+    assert (z * (1 - m)).abs().max() == 0
+    assert (m_p * (1 - m)).abs().max() == 0 and (logs_p * (1 - m)).abs().max() == 0
+    assert x_mask.sum(dim=(1, 2)).cpu().tolist() == batch["frame_lengths"].tolist()
+    assert o.shape[-1] == 512 * int(batch["frame_lengths"].max())

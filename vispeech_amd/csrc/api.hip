@@ -1,0 +1,703 @@
+// C-ABI of libvispeech_hip (include/vispeech_hip.h): context, weights, and the launch sequences
+// that restate SynthesizerTrn.infer (reference models.py:672-722) as HIP kernel launches on the
+// caller's stream.  No allocation and no host synchronisation happens on these paths except
+// vsp_frame_lengths_host.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "model.h"
+
+using namespace vsp;
+
+namespace {
+
+struct T3 {
+  float* p = nullptr;
+  long bs = 0, cs = 0;
+  T3 chan(int c) const { return T3{p ? p + (size_t)c * cs : nullptr, bs, cs}; }
+};
+
+// Bump allocator over the caller's workspace; in dry mode it only measures.
+struct Ws {
+  char* base;
+  size_t cap;
+  size_t cur = 0;
+  bool dry;
+  bool overflow = false;
+  Ws(void* b, size_t c, bool d) : base((char*)b), cap(c), dry(d) {}
+  void* bytes(size_t n) {
+    const size_t o = cur;
+    cur += (n + 255) / 256 * 256;
+    if (dry) return nullptr;
+    if (cur > cap) { overflow = true; return nullptr; }
+    return base + o;
+  }
+  float* f(size_t n) { return (float*)bytes(n * sizeof(float)); }
+  T3 t3(int B, int C, int T) {
+    const long ts = (T + 63) / 64 * 64;
+    T3 t;
+    t.p = f((size_t)B * C * ts);
+    t.cs = ts;
+    t.bs = (long)C * ts;
+    return t;
+  }
+};
+
+inline T3 ext(const float* p, int C, int T) { return T3{const_cast<float*>(p), (long)C * T, (long)T}; }
+
+struct Run {
+  vsp_ctx* ctx;
+  hipStream_t s;
+  Ws& ws;
+  int rc = VSP_OK;
+  bool dry() const { return ws.dry; }
+  const float* A(size_t off) const { return ctx->arena + off; }
+  bool ok() const { return rc == VSP_OK; }
+  void chk(hipError_t e, const char* what) {
+    if (e != hipSuccess && rc == VSP_OK) rc = ctx->fail(VSP_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+  }
+
+  ConvArgs args(const Conv& L, T3 x, T3 out, int T_in, int Nq) const {
+    ConvArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.x = x.p; a.x_bs = x.bs; a.x_cs = x.cs;
+    a.wp = A(L.w);
+    a.bias = L.b >= 0 ? A((size_t)L.b) : nullptr;
+    a.out = out.p; a.o_bs = out.bs; a.o_cs = out.cs;
+    a.Cin = L.Cin; a.M = L.M; a.K = L.K; a.dil = L.dil; a.pad = L.pad;
+    a.T_in = T_in; a.Nq = Nq;
+    a.nchunks = (L.Cin + CONV_CK - 1) / CONV_CK;
+    a.alpha = 1.f; a.div = 1.f;
+    a.ups_s = L.ups_s; a.ups_p = L.ups_p;
+    return a;
+  }
+  void conv(const ConvArgs& a, int B, bool profile = false) {
+    if (dry() || !ok()) return;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (profile && ctx->prof_on) {
+      while (ctx->ev_pool.size() < ctx->ev_used + 2) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) { rc = ctx->fail(VSP_ERR_HIP, "hipEventCreate"); return; }
+        ctx->ev_pool.push_back(e);
+      }
+      e0 = ctx->ev_pool[ctx->ev_used++];
+      e1 = ctx->ev_pool[ctx->ev_used++];
+      (void)hipEventRecord(e0, s);
+    }
+    chk(launch_conv(a, B, s), "conv1d_f32_mfma");
+    if (e1) {
+      (void)hipEventRecord(e1, s);
+      ctx->prof_launches += 1;
+      ctx->prof_flops += 2.0 * a.M * a.Cin * a.K * (double)a.Nq * B;
+    }
+  }
+  // cond(g): 1x1 conv on g [B][gin] (T = 1) -> out [B][M]
+  void cond(const Conv& L, const float* g, float* out, int B) {
+    const int gin = L.Cin;
+    ConvArgs a = args(L, T3{const_cast<float*>(g), (long)gin, 1}, T3{out, (long)L.M, 1}, 1, 1);
+    conv(a, B);
+  }
+  void ln(T3 x, T3 res, size_t gamma, size_t beta, T3 y, int B, int C, int T) {
+    if (dry() || !ok()) return;
+    chk(launch_layernorm(x.p, x.bs, x.cs, res.p, res.bs, res.cs, A(gamma), A(beta), y.p, y.bs, y.cs, B, C, T, s),
+        "layernorm");
+  }
+};
+
+// attentions.Encoder.forward (reference attentions.py:35-47).  x_in must already be masked by the
+// caller's semantics (every reference call site passes x * x_mask); it is re-masked on the copy.
+void run_encoder(Run& r, const EncoderW& E, int B, int T, T3 x_in, const int64_t* lengths, T3 y_out) {
+  const vsp_config& c = r.ctx->cfg;
+  const int h = c.hidden_channels, f = c.filter_channels;
+  T3 X = r.ws.t3(B, h, T), S = r.ws.t3(B, h, T), QKV = r.ws.t3(B, 3 * h, T), AT = r.ws.t3(B, h, T),
+     FF = r.ws.t3(B, f, T);
+  // X = x_in * mask  (1x1 identity is not needed: masked copy through the LN-free path)
+  if (!r.dry() && r.ok()) {
+    // masked copy: use the conv-free elementwise path
+    r.chk(launch_copy3(x_in.p, x_in.bs, x_in.cs, X.p, X.bs, X.cs, B, h, T, r.s), "copy");
+  }
+  for (size_t i = 0; i < E.layers.size(); ++i) {
+    const EncLayer& L = E.layers[i];
+    ConvArgs a = r.args(L.qkv, X, QKV, T, T);
+    a.lengths = lengths; a.in_mask = 1;  // x * x_mask feeds the attention (attentions.py:38)
+    r.conv(a, B);
+    if (!r.dry() && r.ok())
+      r.chk(launch_attention(QKV.p, QKV.bs, QKV.cs, r.A(L.ek), r.A(L.ev), lengths, AT.p, AT.bs, AT.cs, B, h,
+                             c.n_heads, T, c.window_size, r.s), "attention");
+    // S = (x*mask for layer 0 | x) + conv_o(att)
+    a = r.args(L.o, AT, S, T, T);
+    a.res = X.p; a.r_bs = X.bs; a.r_cs = X.cs;
+    r.conv(a, B);
+    r.ln(S, T3{}, L.g1, L.b1, X, B, h, T);
+    // FFN (attentions.py:277-285)
+    a = r.args(L.f1, X, FF, T, T);
+    a.lengths = lengths; a.in_mask = 1; a.act = 1;
+    r.conv(a, B);
+    a = r.args(L.f2, FF, S, T, T);
+    a.lengths = lengths; a.in_mask = 1; a.mask_pre = 1;
+    a.res = X.p; a.r_bs = X.bs; a.r_cs = X.cs;
+    r.conv(a, B);
+    r.ln(S, T3{}, L.g2, L.b2, X, B, h, T);
+  }
+  // y = x * mask
+  if (!r.dry() && r.ok())
+    r.chk(launch_copy3(X.p, X.bs, X.cs, y_out.p, y_out.bs, y_out.cs, B, h, T, r.s), "copy");
+}
+
+void mask3(Run& r, T3 x, const int64_t* lengths, int B, int C, int T) {
+  if (r.dry() || !r.ok() || !lengths) return;
+  r.chk(launch_mask3(x.p, x.bs, x.cs, lengths, B, C, T, r.s), "mask");
+}
+
+// Encoder with the masking the reference applies at entry and exit.
+void run_encoder_masked(Run& r, const EncoderW& E, int B, int T, T3 x_in, const int64_t* lengths, T3 y_out) {
+  run_encoder(r, E, B, T, x_in, lengths, y_out);
+  mask3(r, y_out, lengths, B, r.ctx->cfg.hidden_channels, T);
+}
+
+// ResidualCouplingBlock.forward(reverse=True) in place on z [B][inter][T] (reference models.py:202-209,
+// modules.py:324-343, 148-176).
+void run_flow(Run& r, int B, int T, T3 z, const float* g, const int64_t* lengths) {
+  const vsp_config& c = r.ctx->cfg;
+  const Model& m = r.ctx->model;
+  const int h = c.hidden_channels, half = c.inter_channels / 2, fl = c.flow_layers;
+  T3 H = r.ws.t3(B, h, T), ACT = r.ws.t3(B, h, T), OUT = r.ws.t3(B, h, T);
+  float* gc = r.ws.f((size_t)B * 2 * h * fl);
+  for (int i = c.n_flows - 1; i >= 0; --i) {
+    const FlowW& F = m.flows[i];
+    const T3 x0 = F.flipped ? z.chan(half) : z;
+    const T3 x1 = F.flipped ? z : z.chan(half);
+    ConvArgs a = r.args(F.pre, x0, H, T, T);
+    a.lengths = lengths; a.mask_post = 1;
+    r.conv(a, B);
+    r.cond(F.cond, g, gc, B);
+    for (int l = 0; l < fl; ++l) {
+      a = r.args(F.in[l], H, ACT, T, T);
+      a.act = 2; a.cond = gc ? gc + (size_t)l * 2 * h : nullptr; a.cond_bs = 2L * h * fl;
+      r.conv(a, B);
+      if (l < fl - 1) {
+        // skip first (reads ACT only), then the in-place residual update of H
+        a = r.args(F.skip[l], ACT, OUT, T, T);
+        a.acc_prev = l > 0;
+        r.conv(a, B);
+        a = r.args(F.res[l], ACT, H, T, T);
+        a.res = H.p; a.r_bs = H.bs; a.r_cs = H.cs;
+        a.lengths = lengths; a.mask_post = 1;
+        r.conv(a, B);
+      } else {
+        a = r.args(F.skip[l], ACT, OUT, T, T);
+        a.acc_prev = l > 0;
+        a.lengths = lengths; a.mask_post = 1;
+        r.conv(a, B);
+      }
+    }
+    // m = post(out) * mask ; x1 = (x1 - m) * mask
+    a = r.args(F.post, OUT, x1, T, T);
+    a.lengths = lengths; a.mask_pre = 1; a.alpha = -1.f;
+    a.res = x1.p; a.r_bs = x1.bs; a.r_cs = x1.cs;
+    a.mask_post = 1;
+    r.conv(a, B);
+  }
+}
+
+// Generator.forward (reference models.py:271-290).  z [B][inter][T]; in_lengths != null applies
+// the (z * x_mask) of models.py:720 while staging conv_pre's input.
+void run_generator(Run& r, int B, int T, T3 z, const int64_t* in_lengths, const float* g, float* o) {
+  const vsp_config& c = r.ctx->cfg;
+  const Model& m = r.ctx->model;
+  const int c0 = c.upsample_initial_channel, nk = c.n_resblock_kernels;
+  float* gc = r.ws.f((size_t)B * c0);
+  r.cond(m.g_cond, g, gc, B);
+  // buffer sizes: max over stages of C * T
+  size_t mx = (size_t)c0 * ((T + 63) / 64 * 64);
+  {
+    long t = T;
+    for (int i = 0; i < c.n_upsamples; ++i) {
+      t *= c.upsample_rates[i];
+      mx = std::max(mx, (size_t)(c0 >> (i + 1)) * (size_t)((t + 63) / 64 * 64));
+    }
+  }
+  float* buf[5];
+  for (auto& b : buf) b = r.ws.f((size_t)B * mx);
+  auto view = [&](int k, int C, long Tn) {
+    const long ts = (Tn + 63) / 64 * 64;
+    return T3{buf[k], (long)C * ts, ts};
+  };
+  int cur = 0;  // buffer holding the stage input
+  T3 X = view(cur, c0, T);
+  ConvArgs a = r.args(m.g_pre, z, X, T, T);
+  a.lengths = in_lengths; a.in_mask = in_lengths ? 1 : 0;
+  a.cond = gc; a.cond_bs = c0;
+  r.conv(a, B, true);
+  long Tn = T;
+  int ch = c0;
+  for (int i = 0; i < c.n_upsamples; ++i) {
+    const Conv& U = m.ups[i];
+    const long Tout = Tn * U.ups_s;
+    ch = c0 >> (i + 1);
+    // free buffers: all but `cur`
+    int fb[4], nf = 0;
+    for (int k = 0; k < 5; ++k) if (k != cur) fb[nf++] = k;
+    T3 XU = view(fb[0], ch, Tout), T1 = view(fb[1], ch, Tout), YA = view(fb[2], ch, Tout), XS = view(fb[3], ch, Tout);
+    a = r.args(U, X, XU, (int)Tn, (int)Tn + 1);
+    a.in_act = 1; a.in_slope = 0.1f;
+    a.T_store = (int)Tout;
+    r.conv(a, B, true);
+    for (int j = 0; j < nk; ++j) {
+      const ResBlockW& rb = m.rbs[i * nk + j];
+      const int nd = (int)rb.dil.size();
+      for (int d = 0; d < nd; ++d) {
+        const T3 yin = d == 0 ? XU : YA;
+        a = r.args(rb.c1[d], yin, T1, (int)Tout, (int)Tout);
+        a.in_act = 1; a.in_slope = 0.1f;
+        r.conv(a, B, true);
+        const bool last = d == nd - 1;
+        a = r.args(rb.c2[d], T1, last ? XS : YA, (int)Tout, (int)Tout);
+        a.in_act = 1; a.in_slope = 0.1f;
+        a.res = yin.p; a.r_bs = yin.bs; a.r_cs = yin.cs;
+        if (last) {
+          a.acc_prev = j > 0;
+          if (j == nk - 1) a.div = (float)nk;
+        }
+        r.conv(a, B, true);
+      }
+    }
+    cur = fb[3];
+    X = XS;
+    Tn = Tout;
+  }
+  if (!r.dry() && r.ok())
+    r.chk(launch_conv_post(X.p, X.bs, X.cs, r.A(m.post_w), m.post_c, m.post_k, 0.01f, o, Tn, B, (int)Tn, r.s),
+          "conv_post");
+}
+
+int check_ready(vsp_ctx* ctx) {
+  if (!ctx) return VSP_ERR_ARG;
+  if (!ctx->ready) return ctx->fail(VSP_ERR_STATE, "weights not finalised");
+  return VSP_OK;
+}
+
+long total_upsample(const vsp_config& c) {
+  long u = 1;
+  for (int i = 0; i < c.n_upsamples; ++i) u *= c.upsample_rates[i];
+  return u;
+}
+
+}  // namespace
+
+// ============================================================================================
+extern "C" {
+
+int vsp_abi_version(void) { return VSP_ABI_VERSION; }
+
+int vsp_create(const vsp_config* cfg, int device, vsp_ctx** out) {
+  if (!cfg || !out) return VSP_ERR_ARG;
+  vsp_ctx* ctx = new (std::nothrow) vsp_ctx();
+  if (!ctx) return VSP_ERR_ARG;
+  ctx->cfg = *cfg;
+  ctx->device = device;
+  build_schema(ctx->cfg, ctx->schema);
+  const int rc = plan_model(ctx);
+  *out = ctx;  // returned even on failure so that vsp_last_error can be read; caller destroys it
+  return rc;
+}
+
+int vsp_destroy(vsp_ctx* ctx) {
+  if (!ctx) return VSP_ERR_ARG;
+  for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
+  if (ctx->arena && ctx->arena_owned) (void)hipFree(ctx->arena);
+  delete ctx;
+  return VSP_OK;
+}
+
+const char* vsp_last_error(const vsp_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int vsp_set_weight(vsp_ctx* ctx, const char* key, const float* host_data, const int64_t* shape, int ndim) {
+  if (!ctx || !key || !host_data || !shape || ndim < 0 || ndim > 8) return ctx ? ctx->fail(VSP_ERR_ARG, "null argument") : VSP_ERR_ARG;
+  const std::string k(key);
+  if (k.rfind("enc_q.", 0) == 0) return VSP_OK;  // posterior encoder: training / voice conversion only
+  auto it = ctx->schema.find(k);
+  if (it == ctx->schema.end()) {
+    // accept a pre-folded "<x>.weight" where the schema has "<x>.weight_v" (remove_weight_norm'ed checkpoint)
+    auto iv = ctx->schema.find(k + "_v");
+    if (iv == ctx->schema.end()) return ctx->fail(VSP_ERR_KEY, "unknown state_dict key '%s'", key);
+    it = iv;
+  }
+  const SchemaEntry& e = it->second;
+  bool same = (int)e.shape.size() == ndim;
+  for (int i = 0; same && i < ndim; ++i) same = e.shape[i] == shape[i];
+  if (!same) return ctx->fail(VSP_ERR_SHAPE, "shape mismatch for '%s'", key);
+  if (!e.used) return VSP_OK;
+  HostTensor t;
+  t.shape.assign(shape, shape + ndim);
+  t.data.assign(host_data, host_data + t.numel());
+  ctx->raw[k] = std::move(t);
+  ctx->ready = false;
+  return VSP_OK;
+}
+
+int vsp_missing_weights(const vsp_ctx* ctx) {
+  if (!ctx) return VSP_ERR_ARG;
+  int n = 0;
+  for (const auto& kv : ctx->schema) {
+    if (!kv.second.used) continue;
+    if (ctx->raw.count(kv.first)) continue;
+    const std::string& k = kv.first;
+    // weight_g / weight_v are satisfied by a pre-folded weight
+    if (k.size() > 2 && (k.compare(k.size() - 2, 2, "_v") == 0 || k.compare(k.size() - 2, 2, "_g") == 0) &&
+        ctx->raw.count(k.substr(0, k.size() - 2)))
+      continue;
+    ++n;
+  }
+  return n;
+}
+
+int64_t vsp_weight_arena_bytes(const vsp_ctx* ctx) {
+  return ctx ? (int64_t)(ctx->model.total_floats * sizeof(float)) : VSP_ERR_ARG;
+}
+
+static int set_arena(vsp_ctx* ctx, void* dev_arena) {
+  if (ctx->arena && ctx->arena_owned && ctx->arena != dev_arena) (void)hipFree(ctx->arena);
+  if (dev_arena) {
+    ctx->arena = (float*)dev_arena;
+    ctx->arena_owned = false;
+  } else if (!ctx->arena || !ctx->arena_owned) {
+    void* p = nullptr;
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e == hipSuccess) e = hipMalloc(&p, ctx->model.total_floats * sizeof(float));
+    if (e != hipSuccess) return ctx->fail(VSP_ERR_HIP, "hipMalloc(weight arena): %s", hipGetErrorString(e));
+    ctx->arena = (float*)p;
+    ctx->arena_owned = true;
+  }
+  return VSP_OK;
+}
+
+int vsp_finalize_weights(vsp_ctx* ctx, void* dev_arena) {
+  if (!ctx) return VSP_ERR_ARG;
+  if (ctx->model.total_floats == 0) return ctx->fail(VSP_ERR_STATE, "context was not planned (vsp_create failed)");
+  const int miss = vsp_missing_weights(ctx);
+  if (miss) return ctx->fail(VSP_ERR_STATE, "%d infer-path tensors missing", miss);
+  std::vector<float> host;
+  int rc = fill_model(ctx, host);
+  if (rc) return rc;
+  rc = set_arena(ctx, dev_arena);
+  if (rc) return rc;
+  hipError_t e = hipMemcpy(ctx->arena, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e != hipSuccess) return ctx->fail(VSP_ERR_HIP, "hipMemcpy(weight arena): %s", hipGetErrorString(e));
+  ctx->ready = true;
+  return VSP_OK;
+}
+
+int vsp_adopt_packed_weights(vsp_ctx* ctx, void* dev_arena) {
+  if (!ctx || !dev_arena) return ctx ? ctx->fail(VSP_ERR_ARG, "null arena") : VSP_ERR_ARG;
+  if (ctx->model.total_floats == 0) return ctx->fail(VSP_ERR_STATE, "context was not planned");
+  const int rc = set_arena(ctx, dev_arena);
+  if (rc) return rc;
+  ctx->ready = true;
+  return VSP_OK;
+}
+
+int vsp_weight_arena(const vsp_ctx* ctx, void** dev_arena, int64_t* bytes) {
+  if (!ctx || !dev_arena || !bytes) return VSP_ERR_ARG;
+  *dev_arena = ctx->arena;
+  *bytes = (int64_t)(ctx->model.total_floats * sizeof(float));
+  return VSP_OK;
+}
+
+// -------------------------------------------------------------------------------------------- encode
+static int encode_impl(vsp_ctx* ctx, hipStream_t s, Ws& ws, int B, int Tp, const int64_t* phonemes,
+                       const int64_t* lengths, const int64_t* sid, const float* dctl, const float* pctl,
+                       const float* ectl, float dscale, float pscale, float escale, float* x_var, float* g,
+                       float* duration, float* f0, float* energy, int64_t* frame_lengths, int32_t* cum_dur) {
+  const vsp_config& c = ctx->cfg;
+  const Model& m = ctx->model;
+  const int h = c.hidden_channels, gin = c.gin_channels;
+  Run r{ctx, s, ws};
+  const T3 XV = ext(x_var, h, Tp);
+  T3 XE = ws.t3(B, h, Tp), TMP = ws.t3(B, h, Tp);
+  float* cvec = ws.f((size_t)B * h);
+  float* lf0 = ws.f((size_t)B * Tp);
+  float* pred = ws.f((size_t)B * Tp);
+  float* norm_e = ws.f((size_t)B * Tp);
+  // duration-predictor / energy-predictor activations
+  const int fmax_ = std::max(c.dur_filter, c.energy_filter);
+  T3 P1 = ws.t3(B, fmax_, Tp), P2 = ws.t3(B, fmax_, Tp);
+  const bool live = !ws.dry;
+  if (live) {
+    r.chk(launch_gather_rows(sid, r.A(m.emb_g), c.n_speakers, g, B, gin, s), "emb_g");
+    r.chk(launch_embed(phonemes, r.A(m.emb_sym), c.n_vocab, sqrtf((float)h), XE.p, XE.bs, XE.cs, B, h, Tp, s),
+          "symbol_emb");
+  }
+  mask3(r, XE, lengths, B, h, Tp);  // TextEncoder passes x * x_mask (models.py:173)
+  run_encoder_masked(r, m.enc[0], B, Tp, XE, lengths, XV);   // XV = x_enc
+  // ---- duration (models.py:681-688, 119-133)
+  if (dctl) {
+    if (live) r.chk(hipMemcpyAsync(duration, dctl, (size_t)B * Tp * sizeof(float), hipMemcpyDeviceToDevice, s), "dur copy");
+  } else {
+    const int f = c.dur_filter;
+    T3 A1 = P1, A2 = P2;
+    r.cond(m.dur_cond, g, cvec, B);
+    if (live) r.chk(launch_add_cond(XV.p, XV.bs, XV.cs, cvec, h, TMP.p, TMP.bs, TMP.cs, B, h, Tp, s), "add_cond");
+    ConvArgs a = r.args(m.dur_c1, TMP, A1, Tp, Tp);
+    a.lengths = lengths; a.in_mask = 1; a.act = 1;
+    r.conv(a, B);
+    r.ln(A1, T3{}, m.dur_g1, m.dur_b1, A1, B, f, Tp);
+    a = r.args(m.dur_c2, A1, A2, Tp, Tp);
+    a.lengths = lengths; a.in_mask = 1; a.act = 1;
+    r.conv(a, B);
+    r.ln(A2, T3{}, m.dur_g2, m.dur_b2, A2, B, f, Tp);
+    if (live) {
+      r.chk(launch_chan_dot(A2.p, A2.bs, A2.cs, r.A(m.dur_pw), r.A(m.dur_pb), lengths, 1, 1, pred, B, f, Tp, s), "dur proj");
+      r.chk(launch_duration_from_logw(pred, lengths, dscale, duration, B, Tp, s), "duration");
+    }
+  }
+  // ---- pitch (models.py:691-698, 505-514)
+  if (!pctl) {
+    T3 PI = ws.t3(B, h, Tp);
+    r.cond(m.pit_cond, g, cvec, B);
+    if (live) r.chk(launch_add_cond(XV.p, XV.bs, XV.cs, cvec, h, TMP.p, TMP.bs, TMP.cs, B, h, Tp, s), "add_cond");
+    mask3(r, TMP, lengths, B, h, Tp);
+    run_encoder_masked(r, m.enc[1], B, Tp, TMP, lengths, PI);
+    if (live) r.chk(launch_chan_dot(PI.p, PI.bs, PI.cs, r.A(m.pit_pw), r.A(m.pit_pb), lengths, 1, 0, pred, B, h, Tp, s), "proj_f0");
+  }
+  if (live) {
+    r.chk(launch_pitch(pctl, pred, pscale, lf0, f0, B * Tp, s), "pitch");
+    r.chk(launch_prenet_add(XV.p, XV.bs, XV.cs, r.A(m.ppre_w), r.A(m.ppre_b), lf0, B, h, Tp, s), "pitch_prenet");
+  }
+  // ---- energy (models.py:701-708; frame_prior_network.py:104-124: no mask anywhere)
+  if (!ectl) {
+    const int e = c.energy_filter;
+    T3 A1 = P1, A2 = P2;
+    r.cond(m.en_cond, g, cvec, B);
+    if (live) r.chk(launch_add_cond(XV.p, XV.bs, XV.cs, cvec, h, TMP.p, TMP.bs, TMP.cs, B, h, Tp, s), "add_cond");
+    ConvArgs a = r.args(m.en_c1, TMP, A1, Tp, Tp);
+    a.act = 1;
+    r.conv(a, B);
+    r.ln(A1, T3{}, m.en_g1, m.en_b1, A1, B, e, Tp);
+    a = r.args(m.en_c2, A1, A2, Tp, Tp);
+    a.act = 1;
+    r.conv(a, B);
+    r.ln(A2, T3{}, m.en_g2, m.en_b2, A2, B, e, Tp);
+    if (live) r.chk(launch_chan_dot(A2.p, A2.bs, A2.cs, r.A(m.en_lw), r.A(m.en_lb), nullptr, 0, 0, pred, B, e, Tp, s), "energy linear");
+  }
+  if (live) {
+    r.chk(launch_energy(ectl, pred, escale, norm_e, energy, B * Tp, s), "energy");
+    r.chk(launch_prenet_add(XV.p, XV.bs, XV.cs, r.A(m.epre_w), r.A(m.epre_b), norm_e, B, h, Tp, s), "energy_prenet");
+    r.chk(launch_duration_cumsum(duration, cum_dur, frame_lengths, B, Tp, s), "duration cumsum");
+  }
+  if (ws.overflow) return ctx->fail(VSP_ERR_WORKSPACE, "encode workspace too small (need %zu bytes)", ws.cur);
+  return r.rc;
+}
+
+int64_t vsp_encode_workspace_bytes(const vsp_ctx* ctx, int B, int Tp) {
+  if (!ctx || B <= 0 || Tp <= 0) return VSP_ERR_ARG;
+  Ws ws(nullptr, 0, true);
+  encode_impl(const_cast<vsp_ctx*>(ctx), nullptr, ws, B, Tp, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1,
+              1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+  return (int64_t)ws.cur;
+}
+
+int vsp_encode(vsp_ctx* ctx, void* stream, int B, int Tp, const int64_t* phonemes, const int64_t* lengths,
+               const int64_t* sid, const float* duration_ctl, const float* pitch_ctl, const float* energy_ctl,
+               float duration_scale, float pitch_scale, float energy_scale, float* x_var, float* g, float* duration,
+               float* f0, float* energy, int64_t* frame_lengths, int32_t* cum_dur, void* workspace,
+               int64_t workspace_bytes) {
+  int rc = check_ready(ctx);
+  if (rc) return rc;
+  if (B <= 0 || Tp <= 0 || !phonemes || !lengths || !sid || !x_var || !g || !duration || !f0 || !energy ||
+      !frame_lengths || !cum_dur || !workspace)
+    return ctx->fail(VSP_ERR_ARG, "vsp_encode: null or non-positive argument");
+  Ws ws(workspace, (size_t)workspace_bytes, false);
+  return encode_impl(ctx, (hipStream_t)stream, ws, B, Tp, phonemes, lengths, sid, duration_ctl, pitch_ctl, energy_ctl,
+                     duration_scale, pitch_scale, energy_scale, x_var, g, duration, f0, energy, frame_lengths, cum_dur);
+}
+
+int vsp_frame_lengths_host(vsp_ctx* ctx, void* stream, int B, const int64_t* frame_lengths_dev,
+                           int64_t* frame_lengths_host, int64_t* max_frames) {
+  if (!ctx || B <= 0 || !frame_lengths_dev || !frame_lengths_host || !max_frames)
+    return ctx ? ctx->fail(VSP_ERR_ARG, "vsp_frame_lengths_host: bad argument") : VSP_ERR_ARG;
+  hipError_t e = hipMemcpyAsync(frame_lengths_host, frame_lengths_dev, (size_t)B * sizeof(int64_t),
+                                hipMemcpyDeviceToHost, (hipStream_t)stream);
+  if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+  if (e != hipSuccess) return ctx->fail(VSP_ERR_HIP, "frame length read: %s", hipGetErrorString(e));
+  int64_t mx = 0;
+  for (int b = 0; b < B; ++b) mx = std::max(mx, frame_lengths_host[b]);
+  *max_frames = mx;
+  return VSP_OK;
+}
+
+// -------------------------------------------------------------------------------------------- decode
+static int decode_impl(vsp_ctx* ctx, hipStream_t s, Ws& ws, int B, int Tp, int Tf, int max_len, const float* x_var,
+                       const float* g, const int32_t* cum_dur, const int64_t* frame_lengths, const float* noise,
+                       float noise_scale, float* o, uint8_t* x_mask, float* z, float* z_p, float* m_p, float* logs_p) {
+  const vsp_config& c = ctx->cfg;
+  const Model& m = ctx->model;
+  const int h = c.hidden_channels, inter = c.inter_channels;
+  Run r{ctx, s, ws};
+  const bool live = !ws.dry;
+  T3 XF = ws.t3(B, h, Tf), HF = ws.t3(B, h, Tf);
+  if (live) {
+    r.chk(launch_length_regulate(x_var, (long)h * Tp, Tp, cum_dur, XF.p, XF.bs, XF.cs, B, h, Tp, Tf, s), "length_regulate");
+    r.chk(launch_mask_u8(frame_lengths, x_mask, B, Tf, s), "x_mask");
+  }
+  run_encoder_masked(r, m.enc[2], B, Tf, XF, frame_lengths, HF);
+  const T3 MP = ext(m_p, inter, Tf), LP = ext(logs_p, inter, Tf), Z = ext(z, inter, Tf);
+  ConvArgs a = r.args(m.proj_m, HF, MP, Tf, Tf);
+  a.lengths = frame_lengths; a.mask_post = 1;
+  r.conv(a, B);
+  a = r.args(m.proj_s, HF, LP, Tf, Tf);
+  a.lengths = frame_lengths; a.mask_post = 1;
+  r.conv(a, B);
+  if (live) {
+    const long n = (long)B * inter * Tf;
+    r.chk(launch_reparam(m_p, logs_p, noise, noise_scale, z_p, n, s), "reparam");
+    r.chk(hipMemcpyAsync(z, z_p, n * sizeof(float), hipMemcpyDeviceToDevice, s), "z copy");
+  }
+  run_flow(r, B, Tf, Z, g, frame_lengths);
+  const int Tdec = max_len < 0 ? Tf : std::min(Tf, max_len);
+  if (Tdec > 0) run_generator(r, B, Tdec, Z, frame_lengths, g, o);
+  if (ws.overflow) return ctx->fail(VSP_ERR_WORKSPACE, "decode workspace too small (need %zu bytes)", ws.cur);
+  return r.rc;
+}
+
+int64_t vsp_decode_workspace_bytes(const vsp_ctx* ctx, int B, int Tp, int Tf) {
+  if (!ctx || B <= 0 || Tp <= 0 || Tf <= 0) return VSP_ERR_ARG;
+  Ws ws(nullptr, 0, true);
+  decode_impl(const_cast<vsp_ctx*>(ctx), nullptr, ws, B, Tp, Tf, -1, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f,
+              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+  return (int64_t)ws.cur;
+}
+
+int vsp_decode(vsp_ctx* ctx, void* stream, int B, int Tp, int Tf, int max_len, const float* x_var, const float* g,
+               const int32_t* cum_dur, const int64_t* frame_lengths, const float* noise, float noise_scale, float* o,
+               uint8_t* x_mask, float* z, float* z_p, float* m_p, float* logs_p, void* workspace,
+               int64_t workspace_bytes) {
+  int rc = check_ready(ctx);
+  if (rc) return rc;
+  if (B <= 0 || Tp <= 0 || Tf <= 0 || !x_var || !g || !cum_dur || !frame_lengths || !o || !x_mask || !z || !z_p ||
+      !m_p || !logs_p || !workspace)
+    return ctx->fail(VSP_ERR_ARG, "vsp_decode: null or non-positive argument");
+  if (!noise && noise_scale != 0.f) return ctx->fail(VSP_ERR_ARG, "vsp_decode: noise is required when noise_scale != 0");
+  Ws ws(workspace, (size_t)workspace_bytes, false);
+  return decode_impl(ctx, (hipStream_t)stream, ws, B, Tp, Tf, max_len, x_var, g, cum_dur, frame_lengths, noise,
+                     noise_scale, o, x_mask, z, z_p, m_p, logs_p);
+}
+
+// -------------------------------------------------------------------------------------------- stages
+int64_t vsp_encoder_workspace_bytes(const vsp_ctx* ctx, int B, int T) {
+  if (!ctx || B <= 0 || T <= 0) return VSP_ERR_ARG;
+  Ws ws(nullptr, 0, true);
+  Run r{const_cast<vsp_ctx*>(ctx), nullptr, ws};
+  ws.t3(B, ctx->cfg.hidden_channels, T);
+  run_encoder_masked(r, ctx->model.enc[0], B, T, T3{}, nullptr, T3{});
+  return (int64_t)ws.cur;
+}
+
+int vsp_encoder(vsp_ctx* ctx, void* stream, int which, int B, int T, const float* x, const int64_t* lengths, float* y,
+                void* workspace, int64_t workspace_bytes) {
+  int rc = check_ready(ctx);
+  if (rc) return rc;
+  if (which < 0 || which > 2 || B <= 0 || T <= 0 || !x || !lengths || !y || !workspace)
+    return ctx->fail(VSP_ERR_ARG, "vsp_encoder: bad argument");
+  Ws ws(workspace, (size_t)workspace_bytes, false);
+  Run r{ctx, (hipStream_t)stream, ws};
+  const int h = ctx->cfg.hidden_channels;
+  // the reference call sites pass x * x_mask (models.py:173, 469, 511): mask a private copy
+  T3 XI = ws.t3(B, h, T);
+  if (ws.overflow) return ctx->fail(VSP_ERR_WORKSPACE, "encoder workspace too small");
+  r.chk(launch_copy3(x, (long)h * T, T, XI.p, XI.bs, XI.cs, B, h, T, r.s), "copy");
+  mask3(r, XI, lengths, B, h, T);
+  run_encoder_masked(r, ctx->model.enc[which], B, T, XI, lengths, ext(y, h, T));
+  if (ws.overflow) return ctx->fail(VSP_ERR_WORKSPACE, "encoder workspace too small (need %zu bytes)", ws.cur);
+  return r.rc;
+}
+
+int vsp_length_regulate(vsp_ctx* ctx, void* stream, int B, int C, int Tp, int Tf, const float* x, const int32_t* cum_dur,
+                        float* x_frame) {
+  if (!ctx || B <= 0 || C <= 0 || Tp <= 0 || Tf <= 0 || !x || !cum_dur || !x_frame)
+    return ctx ? ctx->fail(VSP_ERR_ARG, "vsp_length_regulate: bad argument") : VSP_ERR_ARG;
+  hipError_t e = launch_length_regulate(x, (long)C * Tp, Tp, cum_dur, x_frame, (long)C * Tf, Tf, B, C, Tp, Tf,
+                                        (hipStream_t)stream);
+  return e == hipSuccess ? VSP_OK : ctx->fail(VSP_ERR_HIP, "length_regulate: %s", hipGetErrorString(e));
+}
+
+int64_t vsp_flow_workspace_bytes(const vsp_ctx* ctx, int B, int Tf) {
+  if (!ctx || B <= 0 || Tf <= 0) return VSP_ERR_ARG;
+  Ws ws(nullptr, 0, true);
+  Run r{const_cast<vsp_ctx*>(ctx), nullptr, ws};
+  run_flow(r, B, Tf, T3{}, nullptr, nullptr);
+  return (int64_t)ws.cur;
+}
+
+int vsp_flow_reverse(vsp_ctx* ctx, void* stream, int B, int Tf, const float* z_p, const float* g,
+                     const int64_t* frame_lengths, float* z, void* workspace, int64_t workspace_bytes) {
+  int rc = check_ready(ctx);
+  if (rc) return rc;
+  if (B <= 0 || Tf <= 0 || !z_p || !g || !frame_lengths || !z || !workspace)
+    return ctx->fail(VSP_ERR_ARG, "vsp_flow_reverse: bad argument");
+  Ws ws(workspace, (size_t)workspace_bytes, false);
+  Run r{ctx, (hipStream_t)stream, ws};
+  const long n = (long)B * ctx->cfg.inter_channels * Tf;
+  r.chk(hipMemcpyAsync(z, z_p, n * sizeof(float), hipMemcpyDeviceToDevice, r.s), "z copy");
+  run_flow(r, B, Tf, ext(z, ctx->cfg.inter_channels, Tf), g, frame_lengths);
+  if (ws.overflow) return ctx->fail(VSP_ERR_WORKSPACE, "flow workspace too small (need %zu bytes)", ws.cur);
+  return r.rc;
+}
+
+int64_t vsp_generator_workspace_bytes(const vsp_ctx* ctx, int B, int T) {
+  if (!ctx || B <= 0 || T <= 0) return VSP_ERR_ARG;
+  Ws ws(nullptr, 0, true);
+  Run r{const_cast<vsp_ctx*>(ctx), nullptr, ws};
+  run_generator(r, B, T, T3{}, nullptr, nullptr, nullptr);
+  return (int64_t)ws.cur;
+}
+
+int vsp_generator(vsp_ctx* ctx, void* stream, int B, int T, const float* z, const float* g, float* o, void* workspace,
+                  int64_t workspace_bytes) {
+  int rc = check_ready(ctx);
+  if (rc) return rc;
+  if (B <= 0 || T <= 0 || !z || !g || !o || !workspace) return ctx->fail(VSP_ERR_ARG, "vsp_generator: bad argument");
+  Ws ws(workspace, (size_t)workspace_bytes, false);
+  Run r{ctx, (hipStream_t)stream, ws};
+  run_generator(r, B, T, ext(z, ctx->cfg.inter_channels, T), nullptr, g, o);
+  if (ws.overflow) return ctx->fail(VSP_ERR_WORKSPACE, "generator workspace too small (need %zu bytes)", ws.cur);
+  return r.rc;
+}
+
+int vsp_rq_spline(void* stream, int64_t n, int nb, const float* x, const float* uw, const float* uh, const float* ud,
+                  int inverse, float tail_bound, float* y, float* logabsdet) {
+  if (n < 0 || !x || !uw || !uh || !ud || !y || !logabsdet) return VSP_ERR_ARG;
+  hipError_t e = launch_rq_spline(n, nb, x, uw, uh, ud, inverse, tail_bound, y, logabsdet, (hipStream_t)stream);
+  return e == hipSuccess ? VSP_OK : (e == hipErrorInvalidValue ? VSP_ERR_UNSUPPORTED : VSP_ERR_HIP);
+}
+
+// -------------------------------------------------------------------------------------------- profiling
+int vsp_profile_enable(vsp_ctx* ctx, int on) {
+  if (!ctx) return VSP_ERR_ARG;
+  ctx->prof_on = on != 0;
+  return VSP_OK;
+}
+
+int vsp_profile_read(vsp_ctx* ctx, int64_t* launches, double* total_ms, double* total_flops, int reset) {
+  if (!ctx || !launches || !total_ms || !total_flops) return VSP_ERR_ARG;
+  double ms = 0.0;
+  for (size_t i = 0; i + 1 < ctx->ev_used; i += 2) {
+    hipError_t e = hipEventSynchronize(ctx->ev_pool[i + 1]);
+    float t = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&t, ctx->ev_pool[i], ctx->ev_pool[i + 1]);
+    if (e != hipSuccess) return ctx->fail(VSP_ERR_HIP, "profile events: %s", hipGetErrorString(e));
+    ms += t;
+  }
+  *launches = ctx->prof_launches;
+  *total_ms = ms;
+  *total_flops = ctx->prof_flops;
+  if (reset) {
+    ctx->ev_used = 0;
+    ctx->prof_launches = 0;
+    ctx->prof_flops = 0.0;
+  }
+  return VSP_OK;
+}
+
+}  // extern "C"

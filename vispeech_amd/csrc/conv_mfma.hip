@@ -1,0 +1,253 @@
+// conv1d (and polyphase ConvTranspose1d) as an implicit GEMM on the gfx950 f32 matrix core.
+//
+//   GEMM view:  M = output rows (channels, or (channel,phase) pairs for the transposed conv),
+//               N = time, K = (tap, input channel).
+//   v_mfma_f32_32x32x2_f32: A lane l holds A[row l&31][k l>>5], B lane l holds B[k l>>5][col l&31],
+//   D register r of lane l is row (r&3)+8*(r>>2)+4*(l>>5), column l&31.  The product is an exact
+//   f32 fmaf chain in k order, so results track the reference's fp32 convolution to rounding.
+//
+//   * the input tile x[ci chunk][t0-pad .. t0+BN+(K-1)dil) is staged ONCE per chunk into LDS with the
+//     prologue (mask, leaky-relu) applied at staging time, so every tap re-reads activated values
+//     from LDS (conflict-free: a half-wave reads 32 consecutive floats of one row);
+//   * the weights never touch LDS: they are pre-packed on the host in A-fragment order so that a
+//     wave fetches four k-steps of one 32-row tile with a single coalesced 1 KiB global_load_dwordx4
+//     (L2-resident; prefetched one tap ahead);
+//   * the epilogue (bias, conditioning, relu / WN gate, masks, residual, accumulate, divide,
+//     polyphase scatter) runs on the accumulators, so every conv layer is one HBM read + one write.
+//
+// Reference call sites this kernel serves: modules.py:148-176 (WN), :210-223 (ResBlock1),
+// :324-343 (coupling pre/post), attentions.py:138-145, 277-285 (1x1 projections, FFN),
+// models.py:119-133, 271-290, 526-529; frame_prior_network.py:50-55.
+#include "kernels.h"
+
+#include <cstring>
+
+namespace vsp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+size_t packed_conv_floats(int M, int Cin, int K) {
+  const size_t mt = (M + 31) / 32, nc = (Cin + CONV_CK - 1) / CONV_CK;
+  return mt * nc * (size_t)K * 1024;
+}
+
+void pack_conv_weights(float* dst, int M, int Cin, int K, const float* dense) {
+  const int nc = (Cin + CONV_CK - 1) / CONV_CK;
+  std::memset(dst, 0, packed_conv_floats(M, Cin, K) * sizeof(float));
+  for (int row = 0; row < M; ++row) {
+    const int mtile = row >> 5, rin = row & 31;
+    for (int ci = 0; ci < Cin; ++ci) {
+      const int chunk = ci / CONV_CK, cc = ci % CONV_CK;
+      const int kk = cc >> 1, hh = cc & 1, lane = rin + 32 * hh, kg = kk >> 2, i = kk & 3;
+      for (int tap = 0; tap < K; ++tap) {
+        const size_t idx =
+            (((((size_t)mtile * nc + chunk) * K + tap) * (CONV_CK / 8) + kg) * 64 + lane) * 4 + i;
+        dst[idx] = dense[((size_t)row * Cin + ci) * K + tap];
+      }
+    }
+  }
+}
+
+template <int MT, int NT, int WM, int WN>
+__global__ void __launch_bounds__(64 * WM * WN) conv1d_f32_mfma(ConvArgs a) {
+  constexpr int BN = 32 * NT * WN;
+  constexpr int LWP = BN + CONV_HALO;
+  constexpr int NW = WM * WN;
+  constexpr int KG = CONV_CK / 8;
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // [CONV_CK][LWP]
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int b = blockIdx.z;
+  const int t0 = blockIdx.x * BN;
+  const int mtile0 = (blockIdx.y * WM + wm) * MT;
+  const int n_mtiles = (a.M + 31) >> 5;
+  const int len = a.lengths ? (int)a.lengths[b] : 0x7fffffff;
+  const int LW = BN + (a.K - 1) * a.dil;
+  const int total_it = a.nchunks * a.K;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  const float4* wp4 = reinterpret_cast<const float4*>(a.wp);
+  float4 a_cur[MT][KG], a_nxt[MT][KG];
+  auto load_a = [&](int it, float4(&dst)[MT][KG]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int mtile = mtile0 + mt;
+      if (mtile < n_mtiles) {
+        // it = chunk*K + tap, and the packed order is [mtile][chunk][tap][kg][lane]
+        const float4* p = wp4 + (((size_t)mtile * total_it + it) * KG) * 64 + lane;
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) dst[mt][kg] = p[kg * 64];
+      } else {
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) dst[mt][kg] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+  load_a(0, a_cur);
+
+  const float* xb = a.x + (size_t)b * a.x_bs;
+  const float* xsb = xs + h * LWP + wn * (NT * 32) + l31;
+  int it = 0;
+  for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+    // ---- stage x[chunk] -> LDS with the prologue applied
+    for (int c = wave; c < CONV_CK; c += NW) {
+      const int ci = chunk * CONV_CK + c;
+      const bool cvalid = ci < a.Cin;
+      const float* xr = xb + (size_t)ci * a.x_cs;
+      float* dst = xs + c * LWP;
+      for (int col = lane; col < LW; col += 64) {
+        const int t = t0 - a.pad + col;
+        float v = 0.f;
+        if (cvalid && t >= 0 && t < a.T_in) {
+          v = xr[t];
+          if (a.in_mask && t >= len) v = 0.f;
+          if (a.in_act) v = v > 0.f ? v : v * a.in_slope;
+        }
+        dst[col] = v;
+      }
+    }
+    __syncthreads();
+    for (int tap = 0; tap < a.K; ++tap, ++it) {
+      if (it + 1 < total_it) load_a(it + 1, a_nxt);
+      const float* xt = xsb + tap * a.dil;
+#pragma unroll
+      for (int kg = 0; kg < KG; ++kg) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int kk = kg * 4 + i;
+          float bv[NT];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) bv[nt] = xt[(2 * kk) * LWP + nt * 32];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const float av = i == 0 ? a_cur[mt][kg].x : i == 1 ? a_cur[mt][kg].y : i == 2 ? a_cur[mt][kg].z
+                                                                                         : a_cur[mt][kg].w;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[nt], acc[mt][nt], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) a_cur[mt][kg] = a_nxt[mt][kg];
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue
+  const float* resb = a.res ? a.res + (size_t)b * a.r_bs : nullptr;
+  float* outb = a.out + (size_t)b * a.o_bs;
+  const float* condb = a.cond ? a.cond + (size_t)b * a.cond_bs : nullptr;
+  if (a.act == 2) {
+    // WN gate (reference commons.py:100-107): tiles (2i, 2i+1) hold the tanh / sigmoid halves.
+    if constexpr (MT % 2 == 0) {
+#pragma unroll
+      for (int mp = 0; mp < MT / 2; ++mp) {
+        const int mtile = mtile0 + 2 * mp;
+        if (mtile + 1 >= n_mtiles) continue;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int q = t0 + (wn * NT + nt) * 32 + l31;
+          if (q >= a.Nq) continue;
+          const bool valid = q < len;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rin = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int ra = mtile * 32 + rin, rb = ra + 32;
+            float va = acc[2 * mp][nt][r], vb = acc[2 * mp + 1][nt][r];
+            if (a.bias) { va += a.bias[ra]; vb += a.bias[rb]; }
+            if (condb) { va += condb[ra]; vb += condb[rb]; }
+            float v = tanhf(va) * (1.f / (1.f + expf(-vb)));
+            if (a.mask_post && !valid) v = 0.f;
+            const int orow = (mtile >> 1) * 32 + rin;
+            outb[(size_t)orow * a.o_cs + q] = v;
+          }
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int mtile = mtile0 + mt;
+    if (mtile >= n_mtiles) continue;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int q = t0 + (wn * NT + nt) * 32 + l31;
+      if (q >= a.Nq) continue;
+      const bool valid = q < len;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = mtile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row >= a.M) continue;
+        float v = acc[mt][nt][r];
+        if (a.bias) v += a.bias[row];
+        if (condb) v += condb[row];
+        if (a.act == 1) v = fmaxf(v, 0.f);
+        if (a.mask_pre && !valid) v = 0.f;
+        if (a.alpha != 1.f) v *= a.alpha;
+        size_t oidx;
+        if (a.ups_s > 0) {
+          const int co = row / a.ups_s, rr = row - co * a.ups_s;
+          const int n = a.ups_s * q + rr - a.ups_p;
+          if (n < 0 || n >= a.T_store) continue;
+          oidx = (size_t)co * a.o_cs + n;
+        } else {
+          oidx = (size_t)row * a.o_cs + q;
+        }
+        if (resb) v += resb[(size_t)row * a.r_cs + q];
+        if (a.acc_prev) v += outb[oidx];
+        if (a.div != 1.f) v /= a.div;
+        if (a.mask_post && !valid) v = 0.f;
+        outb[oidx] = v;
+      }
+    }
+  }
+}
+
+template <int MT, int NT, int WM, int WN>
+static hipError_t launch_tile(const ConvArgs& a, int B, hipStream_t s) {
+  constexpr int BN = 32 * NT * WN, BM = 32 * MT * WM;
+  constexpr size_t lds = (size_t)CONV_CK * (BN + CONV_HALO) * sizeof(float);
+  static bool attr_set = false;
+  auto kern = conv1d_f32_mfma<MT, NT, WM, WN>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  dim3 grid((a.Nq + BN - 1) / BN, (a.M + BM - 1) / BM, B);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_conv(const ConvArgs& a, int B, hipStream_t s) {
+  if ((a.K - 1) * a.dil > CONV_HALO || a.K < 1 || a.Nq <= 0 || B <= 0) return hipErrorInvalidValue;
+  const bool gate = a.act == 2;
+  if (a.M <= 32 && !gate) {
+    if (a.Nq >= 1024) return launch_tile<1, 4, 1, 4>(a, B, s);
+    return launch_tile<1, 1, 1, 2>(a, B, s);
+  }
+  if (a.Nq <= 96) return launch_tile<2, 1, 1, 2>(a, B, s);
+  if (a.M <= 64 || (a.M % 128 != 0 && a.M < 256)) {
+    if (a.Nq >= 1024) return launch_tile<2, 4, 1, 4>(a, B, s);
+    return launch_tile<2, 1, 1, 4>(a, B, s);
+  }
+  return launch_tile<2, 2, 2, 2>(a, B, s);
+}
+
+}  // namespace vsp

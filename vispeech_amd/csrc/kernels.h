@@ -1,0 +1,104 @@
+// Internal kernel launch interface of libvispeech_hip (gfx950).  Not part of the C-ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vsp {
+
+// ------------------------------------------------------------------------------------------
+// conv1d as implicit GEMM on v_mfma_f32_32x32x2_f32 (exact f32 fmaf chain).
+//   out[b][row][q] = epilogue( sum_{ci,tap} Wp[row][ci][tap] * prologue(x[b][ci][q - pad + tap*dil]) )
+// Weights are pre-packed in MFMA A-fragment order by pack_conv_weights() (host).
+constexpr int CONV_CK = 32;    // input channels staged per LDS chunk
+constexpr int CONV_HALO = 64;  // max (K-1)*dil
+
+struct ConvArgs {
+  const float* x; long x_bs, x_cs;
+  const float* wp;            // packed weights
+  const float* bias;          // [M] per packed row, or null
+  float* out; long o_bs, o_cs;
+  const float* res; long r_bs, r_cs;
+  const float* cond; long cond_bs;   // cond[b*cond_bs + row] added after bias, or null
+  const int64_t* lengths;     // [B] valid length (mask = t < lengths[b]), or null
+  int Cin, M, K, dil, pad;
+  int T_in;                   // input extent (zero padding outside [0,T_in))
+  int Nq;                     // output columns computed
+  int nchunks;                // ceil(Cin / CONV_CK)
+  // prologue on the staged input
+  int in_mask;                // x * mask
+  int in_act; float in_slope; // leaky_relu(x, slope) (slope 0 = relu)
+  // epilogue
+  int act;                    // 0 none, 1 relu, 2 gate: tanh(tile 2i) * sigmoid(tile 2i+1)
+  int mask_pre;
+  float alpha;                // v *= alpha
+  int acc_prev;               // v += out (read-modify-write)
+  float div;                  // v /= div
+  int mask_post;
+  int ups_s, ups_p, T_store;  // transposed-conv store: row=(co,r), n = s*q + r - p in [0,T_store)
+};
+
+struct ConvShape { int bm, bn; };
+// tile: 0 = auto (chosen from M and Nq)
+hipError_t launch_conv(const ConvArgs& a, int B, hipStream_t s);
+size_t packed_conv_floats(int M, int Cin, int K);
+// W(row, ci, tap) accessor -> packed buffer (host).  dst has packed_conv_floats(M,Cin,K) floats.
+void pack_conv_weights(float* dst, int M, int Cin, int K, const float* dense /* [M][Cin][K] */);
+
+// ------------------------------------------------------------------------------------------
+// attention with windowed relative position (reference attentions.py:148-179), f32 MFMA.
+// qkv [B][3*H][T]: rows [0,H) = q, [H,2H) = k, [2H,3H) = v; out [B][H][T].
+hipError_t launch_attention(const float* qkv, long qkv_bs, long qkv_cs, const float* emb_k,
+                            const float* emb_v, const int64_t* lengths, float* out, long o_bs,
+                            long o_cs, int B, int H, int n_heads, int T, int window, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------
+// small kernels (misc.hip)
+// y = LN_channels(x (+ res)) * gamma + beta  (reference modules.py:29-32), eps 1e-5
+hipError_t launch_layernorm(const float* x, long x_bs, long x_cs, const float* res, long r_bs, long r_cs,
+                            const float* gamma, const float* beta, float* y, long y_bs, long y_cs,
+                            int B, int C, int T, hipStream_t s);
+// x[b][c][t] = emb[ids[b][t]][c] * scale
+hipError_t launch_embed(const int64_t* ids, const float* emb, int n_vocab, float scale, float* x,
+                        long x_bs, long x_cs, int B, int C, int T, hipStream_t s);
+// g[b][c] = table[sid[b]][c]
+hipError_t launch_gather_rows(const int64_t* idx, const float* table, int n_rows, float* out, int B, int C,
+                              hipStream_t s);
+// y[b][c][t] = x[b][c][t] + c[b][c]  (optionally * mask)
+hipError_t launch_add_cond(const float* x, long x_bs, long x_cs, const float* cond, long cond_bs, float* y,
+                           long y_bs, long y_cs, int B, int C, int T, hipStream_t s);
+// out[b][t] = bias + sum_c w[c] * x[b][c][t] (* mask_in on x, * mask_out on result)
+hipError_t launch_chan_dot(const float* x, long x_bs, long x_cs, const float* w, const float* bias,
+                           const int64_t* lengths, int mask_in, int mask_out, float* out, int B, int C, int T,
+                           hipStream_t s);
+// x[b][c][t] += bias[c] + sum_j w[c][j] * s[b][t + j - 1]   (Conv1d(1,C,3,padding=1), unmasked)
+hipError_t launch_prenet_add(float* x, long x_bs, long x_cs, const float* w, const float* bias,
+                             const float* sig, int B, int C, int T, hipStream_t s);
+// duration / F0 / energy formulas (reference models.py:681-708)
+hipError_t launch_duration_from_logw(const float* logw, const int64_t* lengths, float scale, float* dur,
+                                     int B, int T, hipStream_t s);
+hipError_t launch_pitch(const float* pitch_ctl, const float* lf0_pred, float scale, float* lf0, float* f0,
+                        int n, hipStream_t s);
+hipError_t launch_energy(const float* energy_ctl, const float* e_pred, float scale, float* norm_e,
+                         float* energy, int n, hipStream_t s);
+// cum[b][i] = sum_{k<=i} max(int(d[b][k]),0); frame_lengths[b] = cum[b][Tp-1]
+hipError_t launch_duration_cumsum(const float* dur, int32_t* cum, int64_t* frame_lengths, int B, int Tp,
+                                  hipStream_t s);
+// out[b][c][f] = f < cum[b][Tp-1] ? x[b][c][upper_bound(cum[b], f)] : 0
+hipError_t launch_length_regulate(const float* x, long x_bs, long x_cs, const int32_t* cum, float* out,
+                                  long o_bs, long o_cs, int B, int C, int Tp, int Tf, hipStream_t s);
+// z_p = m_p + noise * exp(logs_p) * noise_scale ; x_mask[b][t] = t < len[b]
+hipError_t launch_reparam(const float* m_p, const float* logs_p, const float* noise, float noise_scale,
+                          float* z_p, long n, hipStream_t s);
+hipError_t launch_mask_u8(const int64_t* lengths, uint8_t* mask, int B, int T, hipStream_t s);
+// o[b][t] = tanh( sum_c sum_j w[c][j] * lrelu(x[b][c][t+j-pad], slope) )  (conv_post, no bias)
+hipError_t launch_conv_post(const float* x, long x_bs, long x_cs, const float* w, int C, int K, float slope,
+                            float* o, long o_bs, int B, int T, hipStream_t s);
+hipError_t launch_copy3(const float* x, long x_bs, long x_cs, float* y, long y_bs, long y_cs, int B, int C,
+                        int T, hipStream_t s);
+// x[b][c][t] = 0 for t >= lengths[b]
+hipError_t launch_mask3(float* x, long x_bs, long x_cs, const int64_t* lengths, int B, int C, int T, hipStream_t s);
+hipError_t launch_rq_spline(int64_t n, int nb, const float* x, const float* uw, const float* uh,
+                            const float* ud, int inverse, float tail_bound, float* y, float* lad,
+                            hipStream_t s);
+
+}  // namespace vsp

@@ -1,0 +1,108 @@
+// Host-side model description of libvispeech_hip: packed-arena plan, schema, context.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/vispeech_hip.h"
+#include "kernels.h"
+
+namespace vsp {
+
+struct HostTensor {
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+  size_t numel() const { size_t n = 1; for (auto s : shape) n *= (size_t)s; return n; }
+};
+
+// One conv layer in the packed arena (offsets in floats from the arena base).
+struct Conv {
+  int M = 0, Cin = 0, K = 1, dil = 1, pad = 0;
+  int ups_s = 0, ups_p = 0;
+  size_t w = 0;
+  long b = -1;
+};
+
+struct EncLayer {
+  Conv qkv, o, f1, f2;
+  size_t ek = 0, ev = 0, g1 = 0, b1 = 0, g2 = 0, b2 = 0;
+};
+struct EncoderW {
+  std::string prefix;
+  std::vector<EncLayer> layers;
+};
+struct FlowW {
+  bool flipped = false;
+  Conv pre, cond, post;
+  std::vector<Conv> in, res, skip;
+};
+struct ResBlockW {
+  int k = 0;
+  std::vector<int> dil;
+  std::vector<Conv> c1, c2;
+};
+
+struct Model {
+  size_t emb_sym = 0, emb_g = 0;
+  EncoderW enc[3];  // 0 enc_p.encoder, 1 pitch_predictor.pitch_net, 2 frame_prior_net.fft_block
+  Conv dur_cond, dur_c1, dur_c2;
+  size_t dur_g1 = 0, dur_b1 = 0, dur_g2 = 0, dur_b2 = 0, dur_pw = 0, dur_pb = 0;
+  Conv pit_cond;
+  size_t pit_pw = 0, pit_pb = 0;
+  Conv en_cond, en_c1, en_c2;
+  size_t en_g1 = 0, en_b1 = 0, en_g2 = 0, en_b2 = 0, en_lw = 0, en_lb = 0;
+  size_t ppre_w = 0, ppre_b = 0, epre_w = 0, epre_b = 0;
+  Conv proj_m, proj_s;
+  std::vector<FlowW> flows;  // index = flow layer i (applied in order n_flows-1 .. 0)
+  Conv g_pre, g_cond;
+  std::vector<Conv> ups;
+  std::vector<ResBlockW> rbs;
+  size_t post_w = 0;
+  int post_k = 7, post_c = 32;
+  size_t total_floats = 0;
+};
+
+struct SchemaEntry {
+  std::vector<int64_t> shape;
+  bool used;
+};
+
+}  // namespace vsp
+
+struct vsp_ctx {
+  vsp_config cfg;
+  int device = 0;
+  std::string err;
+  std::map<std::string, vsp::SchemaEntry> schema;
+  std::map<std::string, vsp::HostTensor> raw;
+  vsp::Model model;
+  float* arena = nullptr;
+  bool arena_owned = false;
+  bool ready = false;
+  // profiling of the dominant kernel
+  bool prof_on = false;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  int64_t prof_launches = 0;
+  double prof_flops = 0.0;
+
+  int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    err = buf;
+    return code;
+  }
+};
+
+namespace vsp {
+void build_schema(const vsp_config& c, std::map<std::string, SchemaEntry>& out);
+int plan_model(vsp_ctx* ctx);                         // fills ctx->model offsets from cfg
+int fill_model(vsp_ctx* ctx, std::vector<float>& host_arena);  // folds + packs ctx->raw
+}  // namespace vsp

@@ -1,0 +1,250 @@
+"""Thin torch-side driver of the C-ABI: owns a ``vsp_ctx``, hands torch CUDA tensors' pointers to
+libvispeech_hip and keeps the caller-owned workspaces.  torch is plumbing here (device memory,
+the current HIP stream); every arithmetic step runs in the library's kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Mapping, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .schema import ModelDims, used_by_infer
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _dev_f32(t, device) -> torch.Tensor:
+    return torch.as_tensor(t).to(device=device, dtype=torch.float32).contiguous()
+
+
+def _dev_i64(t, device) -> torch.Tensor:
+    return torch.as_tensor(t).to(device=device, dtype=torch.int64).contiguous()
+
+
+class Engine:
+    def __init__(self, dims: ModelDims, device: "torch.device | str | int" = "cuda:0"):
+        self.lib = _lib.lib()                      # raises ImportError if the extension is absent
+        self.dims = dims
+        self.device = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
+        if self.device.type != "cuda":
+            raise RuntimeError("vispeech_amd runs on an MI355X (torch device 'cuda'); there is no CPU path")
+        self.cfg = _lib.make_config(dims)
+        ctx = C.c_void_p()
+        rc = self.lib.vsp_create(C.byref(self.cfg), self.device.index or 0, C.byref(ctx))
+        self.ctx = ctx
+        _lib.check(rc, ctx, "vsp_create")
+        self._arena: Optional[torch.Tensor] = None
+        self._ws: Dict[str, torch.Tensor] = {}
+        self.ready = False
+
+    def __del__(self):
+        try:
+            if getattr(self, "ctx", None):
+                self.lib.vsp_destroy(self.ctx)
+                self.ctx = None
+        except Exception:  # pragma: no cover
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def set_weights(self, state_dict: Mapping[str, "np.ndarray | torch.Tensor"], strict: bool = True):
+        missing, unexpected = [], []
+        for k, v in state_dict.items():
+            a = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            shape = (C.c_int64 * max(a.ndim, 1))(*a.shape)
+            rc = self.lib.vsp_set_weight(self.ctx, k.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim)
+            if rc == -4:
+                unexpected.append(k)
+                continue
+            _lib.check(rc, self.ctx, f"vsp_set_weight({k})")
+        n_missing = self.lib.vsp_missing_weights(self.ctx)
+        if n_missing:
+            missing.append(f"{n_missing} infer-path tensors")
+        if strict and (unexpected or n_missing):
+            raise RuntimeError(f"load_state_dict: unexpected keys {unexpected[:5]}..., missing {missing}")
+        return missing, unexpected
+
+    def arena_bytes(self) -> int:
+        return int(self.lib.vsp_weight_arena_bytes(self.ctx))
+
+    def _alloc_arena(self) -> torch.Tensor:
+        if self._arena is None:
+            self._arena = torch.empty(self.arena_bytes() // 4, dtype=torch.float32, device=self.device)
+        return self._arena
+
+    def finalize(self) -> torch.Tensor:
+        """Fold, pack and upload; returns the packed arena as a flat float tensor (the object a
+        multi-GPU run broadcasts from rank 0)."""
+        arena = self._alloc_arena()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.vsp_finalize_weights(self.ctx, _ptr(arena)), self.ctx, "vsp_finalize_weights")
+        self.ready = True
+        return arena
+
+    def adopt(self, arena: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Non-root rank: use an arena whose bytes arrive by broadcast."""
+        if arena is None:
+            arena = self._alloc_arena()
+        assert arena.numel() * 4 == self.arena_bytes() and arena.is_cuda
+        self._arena = arena
+        _lib.check(self.lib.vsp_adopt_packed_weights(self.ctx, _ptr(arena)), self.ctx, "vsp_adopt_packed_weights")
+        self.ready = True
+        return arena
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _workspace(self, tag: str, nbytes: int) -> torch.Tensor:
+        if nbytes < 0:
+            _lib.check(int(nbytes), self.ctx, f"{tag} workspace size")
+        w = self._ws.get(tag)
+        if w is None or w.numel() < nbytes:
+            self._ws[tag] = None
+            w = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
+            self._ws[tag] = w
+        return w
+
+    def _f(self, *shape) -> torch.Tensor:
+        return torch.empty(shape, dtype=torch.float32, device=self.device)
+
+    # ------------------------------------------------------------------ the path
+    def encode(self, phonemes, lengths, sid, duration_ctl=None, pitch_ctl=None, energy_ctl=None,
+               duration_scale=1.0, pitch_scale=1.0, energy_scale=1.0) -> Dict[str, torch.Tensor]:
+        d = self.dims
+        ph = _dev_i64(phonemes, self.device)
+        ln = _dev_i64(lengths, self.device)
+        sd = _dev_i64(sid, self.device)
+        B, Tp = ph.shape
+        dc = None if duration_ctl is None else _dev_f32(duration_ctl, self.device).reshape(B, -1)
+        pc = None if pitch_ctl is None else _dev_f32(pitch_ctl, self.device).reshape(B, -1)
+        ec = None if energy_ctl is None else _dev_f32(energy_ctl, self.device).reshape(B, -1)
+        for name, t in (("duration", dc), ("pitch", pc), ("energy", ec)):
+            if t is not None and t.shape[1] != Tp:
+                raise ValueError(f"{name}_control must have {Tp} entries per utterance, got {t.shape[1]}")
+        out = dict(x_var=self._f(B, d.hidden_channels, Tp), g=self._f(B, d.gin_channels),
+                   duration=self._f(B, Tp), F0=self._f(B, Tp), energy=self._f(B, Tp),
+                   frame_lengths=torch.empty(B, dtype=torch.int64, device=self.device),
+                   cum_dur=torch.empty(B, Tp, dtype=torch.int32, device=self.device))
+        ws = self._workspace("encode", self.lib.vsp_encode_workspace_bytes(self.ctx, B, Tp))
+        with torch.cuda.device(self.device):
+            rc = self.lib.vsp_encode(self.ctx, self._stream(), B, Tp, _ptr(ph), _ptr(ln), _ptr(sd), _ptr(dc), _ptr(pc),
+                                     _ptr(ec), float(duration_scale), float(pitch_scale), float(energy_scale),
+                                     _ptr(out["x_var"]), _ptr(out["g"]), _ptr(out["duration"]), _ptr(out["F0"]),
+                                     _ptr(out["energy"]), _ptr(out["frame_lengths"]), _ptr(out["cum_dur"]), _ptr(ws),
+                                     ws.numel())
+        _lib.check(rc, self.ctx, "vsp_encode")
+        out["_keep"] = (ph, ln, sd, dc, pc, ec)
+        return out
+
+    def frame_lengths_host(self, frame_lengths: torch.Tensor):
+        B = frame_lengths.numel()
+        host = (C.c_int64 * B)()
+        mx = C.c_int64()
+        with torch.cuda.device(self.device):
+            rc = self.lib.vsp_frame_lengths_host(self.ctx, self._stream(), B, _ptr(frame_lengths), host, C.byref(mx))
+        _lib.check(rc, self.ctx, "vsp_frame_lengths_host")
+        return list(host), int(mx.value)
+
+    def decode(self, enc: Mapping[str, torch.Tensor], Tf: int, noise: Optional[torch.Tensor], noise_scale: float,
+               max_len: Optional[int] = None) -> Dict[str, torch.Tensor]:
+        d = self.dims
+        B, _, Tp = enc["x_var"].shape
+        inter = d.inter_channels
+        Tdec = Tf if max_len is None else max(min(Tf, int(max_len)), 0)
+        if noise is not None:
+            noise = _dev_f32(noise, self.device)
+            if tuple(noise.shape) != (B, inter, Tf):
+                raise ValueError(f"noise must be [{B},{inter},{Tf}], got {tuple(noise.shape)}")
+        out = dict(o=self._f(B, 1, Tdec * d.total_upsample),
+                   x_mask=torch.empty(B, 1, Tf, dtype=torch.uint8, device=self.device),
+                   z=self._f(B, inter, Tf), z_p=self._f(B, inter, Tf), m_p=self._f(B, inter, Tf),
+                   logs_p=self._f(B, inter, Tf))
+        ws = self._workspace("decode", self.lib.vsp_decode_workspace_bytes(self.ctx, B, Tp, Tf))
+        with torch.cuda.device(self.device):
+            rc = self.lib.vsp_decode(self.ctx, self._stream(), B, Tp, Tf, -1 if max_len is None else int(max_len),
+                                     _ptr(enc["x_var"]), _ptr(enc["g"]), _ptr(enc["cum_dur"]),
+                                     _ptr(enc["frame_lengths"]), _ptr(noise), float(noise_scale), _ptr(out["o"]),
+                                     _ptr(out["x_mask"]), _ptr(out["z"]), _ptr(out["z_p"]), _ptr(out["m_p"]),
+                                     _ptr(out["logs_p"]), _ptr(ws), ws.numel())
+        _lib.check(rc, self.ctx, "vsp_decode")
+        out["x_mask"] = out["x_mask"].view(torch.bool) if hasattr(torch, "bool") else out["x_mask"]
+        return out
+
+    # ------------------------------------------------------------------ per-stage entry points
+    def encoder(self, which: int, x, lengths) -> torch.Tensor:
+        x = _dev_f32(x, self.device)
+        ln = _dev_i64(lengths, self.device)
+        B, h, T = x.shape
+        y = self._f(B, h, T)
+        ws = self._workspace("encoder", self.lib.vsp_encoder_workspace_bytes(self.ctx, B, T))
+        with torch.cuda.device(self.device):
+            rc = self.lib.vsp_encoder(self.ctx, self._stream(), which, B, T, _ptr(x), _ptr(ln), _ptr(y), _ptr(ws),
+                                      ws.numel())
+        _lib.check(rc, self.ctx, "vsp_encoder")
+        return y
+
+    def length_regulate(self, x, cum_dur, Tf: int) -> torch.Tensor:
+        x = _dev_f32(x, self.device)
+        cum = torch.as_tensor(cum_dur).to(device=self.device, dtype=torch.int32).contiguous()
+        B, Cc, Tp = x.shape
+        y = self._f(B, Cc, Tf)
+        with torch.cuda.device(self.device):
+            rc = self.lib.vsp_length_regulate(self.ctx, self._stream(), B, Cc, Tp, Tf, _ptr(x), _ptr(cum), _ptr(y))
+        _lib.check(rc, self.ctx, "vsp_length_regulate")
+        return y
+
+    def flow_reverse(self, z_p, g, frame_lengths) -> torch.Tensor:
+        z_p = _dev_f32(z_p, self.device)
+        g = _dev_f32(g, self.device).reshape(z_p.shape[0], -1)
+        fl = _dev_i64(frame_lengths, self.device)
+        B, _, Tf = z_p.shape
+        z = torch.empty_like(z_p)
+        ws = self._workspace("flow", self.lib.vsp_flow_workspace_bytes(self.ctx, B, Tf))
+        with torch.cuda.device(self.device):
+            rc = self.lib.vsp_flow_reverse(self.ctx, self._stream(), B, Tf, _ptr(z_p), _ptr(g), _ptr(fl), _ptr(z),
+                                           _ptr(ws), ws.numel())
+        _lib.check(rc, self.ctx, "vsp_flow_reverse")
+        return z
+
+    def generator(self, z, g) -> torch.Tensor:
+        z = _dev_f32(z, self.device)
+        g = _dev_f32(g, self.device).reshape(z.shape[0], -1)
+        B, _, T = z.shape
+        o = self._f(B, 1, T * self.dims.total_upsample)
+        ws = self._workspace("generator", self.lib.vsp_generator_workspace_bytes(self.ctx, B, T))
+        with torch.cuda.device(self.device):
+            rc = self.lib.vsp_generator(self.ctx, self._stream(), B, T, _ptr(z), _ptr(g), _ptr(o), _ptr(ws), ws.numel())
+        _lib.check(rc, self.ctx, "vsp_generator")
+        return o
+
+    def profile(self, on: bool) -> None:
+        _lib.check(self.lib.vsp_profile_enable(self.ctx, int(on)), self.ctx, "vsp_profile_enable")
+
+    def profile_read(self, reset: bool = True):
+        n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
+        _lib.check(self.lib.vsp_profile_read(self.ctx, C.byref(n), C.byref(ms), C.byref(fl), int(reset)), self.ctx,
+                   "vsp_profile_read")
+        return int(n.value), float(ms.value), float(fl.value)
+
+
+def rq_spline(x, uw, uh, ud, inverse: bool = False, tail_bound: float = 5.0):
+    """piecewise_rational_quadratic_transform(..., tails='linear') on the GPU (reference
+    transforms.py:12-193).  x [...]; uw, uh [..., nb]; ud [..., nb-1]."""
+    l = _lib.lib()
+    dev = torch.device("cuda", torch.cuda.current_device()) if not (torch.is_tensor(x) and x.is_cuda) else x.device
+    x = _dev_f32(x, dev)
+    uw, uh, ud = _dev_f32(uw, dev), _dev_f32(uh, dev), _dev_f32(ud, dev)
+    nb = uw.shape[-1]
+    n = x.numel()
+    y, lad = torch.empty_like(x), torch.empty_like(x)
+    with torch.cuda.device(dev):
+        rc = l.vsp_rq_spline(C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), n, nb, _ptr(x), _ptr(uw), _ptr(uh),
+                             _ptr(ud), int(inverse), float(tail_bound), _ptr(y), _ptr(lad))
+    _lib.check(rc, None, "vsp_rq_spline")
+    return y, lad
