@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X synthesis path: 44.1 kHz output samples/s (and RTF) of
+SynthesizerTrn.infer on the BASELINE.json headline workload (C3: a 64-utterance mixed zh/ja
+batch of ~5 s utterances, phoneme/duration/F0/energy/noise supplied), one process per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one full infer() of the rank's 64-utterance batch with all inputs resident in HBM.
+For N > 1 every rank runs its own 64-utterance shard (weak scaling, seeds 103 + rank) padded to
+the GLOBAL frame count (one int all-reduce MAX, SURVEY gotcha G6), and the step ends with the
+gather of the waveforms on rank 0 over RCCL -- the exchange the north star names.  Packed
+weights are broadcast from rank 0 once, before timing.  value = valid samples of all ranks / time.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+ALG_BYTES_PER_SAMPLE = 13045     # SURVEY.md 8(d), fp32 end-to-end layer-boundary traffic
+ALG_FLOPS_PER_SAMPLE = 1.641e6
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=3)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--workload", default="C3")
+    p.add_argument("--batch", type=int, default=None, help="override utterances per GPU (debug)")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-sample", type=int, default=2, help="utterances of the batch timed on the CPU oracle")
+    return p.parse_args()
+
+
+def cpu_baseline(sd, dims, batch, n_utt):
+    """The parity-pinned CPU restatement (oracle/, kind 'port') timed on the host cores on the
+    first n_utt utterances of the same batch."""
+    from oracle.vispeech_oracle import Oracle
+    # threads actually usable by this process (cgroup/affinity), capped: torch's CPU convolutions
+    # stop scaling (and collapse under oversubscription) far below the 256 hardware threads of the host
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 32))
+    torch.set_num_threads(cores)
+    orc = Oracle(sd, dims)
+    sl = slice(0, n_utt)
+    tp = int(batch["lengths"][sl].max())
+    tf = int(batch["frame_lengths"][sl].max())
+    kw = dict(noise=batch["noise"][sl, :, :tf], noise_scale=0.667, duration_control=batch["duration"][sl, :tp],
+              pitch_control=batch["f0"][sl, :tp], energy_control=batch["energy"][sl, :tp])
+    # tiny warm-up (thread pool, mkldnn primitives)
+    orc.infer(batch["phonemes"][:1, :4], np.array([4]), batch["sid"][:1], noise=batch["noise"][:1, :, :8],
+              noise_scale=0.667, duration_control=np.full((1, 4), 2.0, dtype=np.float32),
+              pitch_control=batch["f0"][:1, :4], energy_control=batch["energy"][:1, :4])
+    t0 = time.perf_counter()
+    orc.infer(batch["phonemes"][sl, :tp], batch["lengths"][sl], batch["sid"][sl], **kw)
+    dt = time.perf_counter() - t0
+    samples = 512 * int(batch["frame_lengths"][sl].sum())
+    return {"value": samples / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"first {n_utt} utterances of the same batch ({samples} valid samples, {dt:.1f} s, "
+                      f"oracle/vispeech_oracle.py on torch CPU fp32, {cores} threads)",
+            "rtf": dt / (samples / 44100.0)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    from vispeech_amd import config as vcfg
+    from vispeech_amd.models import SynthesizerTrn
+    from vispeech_amd.schema import ModelDims
+    from vispeech_amd.synth import WORKLOADS, synth_batch, synth_state_dict
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    dims = ModelDims()
+    hps = vcfg.default_hparams()
+    a, kw = vcfg.synthesizer_args(hps)
+    net = SynthesizerTrn(*a, device=dev, **kw).eval()
+    sd = synth_state_dict(dims, seed=1234, infer_only=True) if rank == 0 or world == 1 else None
+    if world == 1:
+        net.load_state_dict(sd)
+    else:
+        # RCCL weight broadcast: rank 0 packs, everyone else adopts the broadcast arena
+        eng = net._engine
+        if rank == 0:
+            eng.set_weights(sd)
+            arena = eng.finalize()
+        else:
+            arena = eng.adopt()
+        dist.broadcast(arena, src=0)
+        torch.cuda.synchronize()
+
+    wl = dict(WORKLOADS[args.workload])
+    wl["seed"] = wl["seed"] + rank
+    if args.batch:
+        wl["batch"] = args.batch
+    batch = synth_batch(**wl)
+    B = int(batch["phonemes"].shape[0])
+    t = lambda x: torch.from_numpy(np.asarray(x)).to(dev)
+    ph, ln, sid = t(batch["phonemes"]), t(batch["lengths"]), t(batch["sid"])
+    dur, f0, en = t(batch["duration"]), t(batch["f0"]), t(batch["energy"])
+    tf_local = int(batch["frame_lengths"].max())
+    valid_samples = 512 * int(batch["frame_lengths"].sum())
+    tf_t = torch.tensor([tf_local], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(tf_t, op=dist.ReduceOp.MAX)
+    tf_global = int(tf_t.item())
+    noise = torch.zeros(B, dims.inter_channels, tf_global, dtype=torch.float32, device=dev)
+    noise[:, :, :tf_local] = t(batch["noise"])
+    gathered = [torch.empty(B, 1, 512 * tf_global, dtype=torch.float32, device=dev) for _ in range(world)] \
+        if (world > 1 and rank == 0) else None
+
+    def step():
+        o, *_ = net.infer(ph, ln, sid=sid, noise_scale=0.667, duration_control=dur, pitch_control=f0,
+                          energy_control=en, noise=noise, t_f=tf_global)
+        if world > 1:
+            dist.gather(o, gathered, dst=0)
+        return o
+
+    for _ in range(args.warmup):
+        step()
+    net._engine.profile(True)
+    net._engine.profile_read(reset=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    launches, conv_ms, conv_flops = net._engine.profile_read(reset=True)
+    net._engine.profile(False)
+
+    tt = torch.tensor([dt, float(valid_samples)], dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = tt.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = tt.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        dt, total_valid = float(mx[0].item()), float(sm[1].item())
+    else:
+        total_valid = float(valid_samples)
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = total_valid * args.steps / dt
+        audio_s = total_valid / 44100.0
+        achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        out = {
+            "metric": "44.1kHz samples/sec", "value": value, "unit": "samples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "rtf": (dt / args.steps) / audio_s,
+            "config": {"workload": f"{args.workload}: {B} mixed zh/ja utterances per GPU (~5 s each, 44.1 kHz, hop 512), "
+                                   "phoneme/duration/F0/energy/noise supplied, random-init (synthetic) weights of "
+                                   "configs/config.json",
+                       "utterances_per_gpu": B, "padded_frames": tf_global,
+                       "valid_samples_per_step": int(total_valid), "parallelism": f"shard{world}"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "conv1d_f32_mfma (generator launches, rank 0)",
+                         "launches": launches, "avg_launch_ms": conv_ms / max(launches, 1),
+                         "alg_flops_per_launch": conv_flops / max(launches, 1),
+                         "hbm_frac_whole_path": value / world * ALG_BYTES_PER_SAMPLE / 8.0e12},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd, dims, batch, min(args.cpu_sample, B))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -15,7 +15,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-STAGE_TOL = 2e-5
+STAGE_TOL = 1e-5
 WAVE_TOL = 1e-4
 
 CASES = ["ragged_controls", "ragged_predictors", "maxlen_dur3d", "c1_filelist"]

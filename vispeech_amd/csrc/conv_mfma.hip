@@ -97,24 +97,61 @@ __global__ void __launch_bounds__(64 * WM * WN) conv1d_f32_mfma(ConvArgs a) {
   load_a(0, a_cur);
 
   const float* xb = a.x + (size_t)b * a.x_bs;
-  const float* xsb = xs + h * LWP + wn * (NT * 32) + l31;
+  // vectorised staging needs 16-byte aligned rows (true for every internal [B][C][Ts] buffer)
+  const bool vec = ((a.x_cs & 3) == 0) && ((a.x_bs & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
+  const int t_start = vec ? (((t0 - a.pad) >> 2) << 2) : (t0 - a.pad);
+  const int off = (t0 - a.pad) - t_start;
+  const int LW4 = (LW + off + 3) >> 2;
+  const float* xsb = xs + h * LWP + wn * (NT * 32) + l31 + off;
   int it = 0;
   for (int chunk = 0; chunk < a.nchunks; ++chunk) {
     // ---- stage x[chunk] -> LDS with the prologue applied
-    for (int c = wave; c < CONV_CK; c += NW) {
-      const int ci = chunk * CONV_CK + c;
-      const bool cvalid = ci < a.Cin;
-      const float* xr = xb + (size_t)ci * a.x_cs;
-      float* dst = xs + c * LWP;
-      for (int col = lane; col < LW; col += 64) {
-        const int t = t0 - a.pad + col;
-        float v = 0.f;
-        if (cvalid && t >= 0 && t < a.T_in) {
-          v = xr[t];
-          if (a.in_mask && t >= len) v = 0.f;
-          if (a.in_act) v = v > 0.f ? v : v * a.in_slope;
+    if (vec) {
+      // 16-byte loads, one row per (wave, j) and all RW rows of a column block in flight at once;
+      // the staged window starts at t_start = floor4(t0 - pad) so every load is 16-byte aligned.
+      constexpr int RW = CONV_CK / NW;
+      for (int q0 = 0; q0 < LW4; q0 += 64) {
+        const int q4 = q0 + lane;
+        const int t4 = t_start + 4 * q4;
+        const bool tin = q4 < LW4 && t4 >= 0 && t4 < a.T_in;
+        float4 v[RW];
+#pragma unroll
+        for (int j = 0; j < RW; ++j) {
+          const int ci = chunk * CONV_CK + wave + j * NW;
+          v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (tin && ci < a.Cin) v[j] = *reinterpret_cast<const float4*>(xb + (size_t)ci * a.x_cs + t4);
         }
-        dst[col] = v;
+        if (q4 < LW4) {
+          const int lim = a.in_mask ? (len < a.T_in ? len : a.T_in) : a.T_in;
+#pragma unroll
+          for (int j = 0; j < RW; ++j) {
+            float e[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              float x = (t4 + u < lim) ? e[u] : 0.f;
+              if (a.in_act) x = x > 0.f ? x : x * a.in_slope;
+              e[u] = x;
+            }
+            *reinterpret_cast<float4*>(xs + (wave + j * NW) * LWP + 4 * q4) = make_float4(e[0], e[1], e[2], e[3]);
+          }
+        }
+      }
+    } else {
+      for (int c = wave; c < CONV_CK; c += NW) {
+        const int ci = chunk * CONV_CK + c;
+        const bool cvalid = ci < a.Cin;
+        const float* xr = xb + (size_t)ci * a.x_cs;
+        float* dst = xs + c * LWP;
+        for (int col = lane; col < LW; col += 64) {
+          const int t = t0 - a.pad + col;
+          float v = 0.f;
+          if (cvalid && t >= 0 && t < a.T_in) {
+            v = xr[t];
+            if (a.in_mask && t >= len) v = 0.f;
+            if (a.in_act) v = v > 0.f ? v : v * a.in_slope;
+          }
+          dst[col] = v;
+        }
       }
     }
     __syncthreads();
@@ -189,30 +226,41 @@ __global__ void __launch_bounds__(64 * WM * WN) conv1d_f32_mfma(ConvArgs a) {
       const int q = t0 + (wn * NT + nt) * 32 + l31;
       if (q >= a.Nq) continue;
       const bool valid = q < len;
+      // all loads of the tile first (res / out_prev may alias out: a load behind a store would
+      // have to wait for that store), then the arithmetic and the stores
+      size_t oidx[16];
+      bool st[16];
+      float rv[16], pv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = mtile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row >= a.M) continue;
+        st[r] = row < a.M;
+        if (a.ups_s > 0) {
+          const int co = row / a.ups_s, rr = row - co * a.ups_s;
+          const int n = a.ups_s * q + rr - a.ups_p;
+          st[r] = st[r] && n >= 0 && n < a.T_store;
+          oidx[r] = (size_t)co * a.o_cs + n;
+        } else {
+          oidx[r] = (size_t)row * a.o_cs + q;
+        }
+        rv[r] = (resb && st[r]) ? resb[(size_t)row * a.r_cs + q] : 0.f;
+        pv[r] = (a.acc_prev && st[r]) ? outb[oidx[r]] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = mtile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (!st[r]) continue;
         float v = acc[mt][nt][r];
         if (a.bias) v += a.bias[row];
         if (condb) v += condb[row];
         if (a.act == 1) v = fmaxf(v, 0.f);
         if (a.mask_pre && !valid) v = 0.f;
         if (a.alpha != 1.f) v *= a.alpha;
-        size_t oidx;
-        if (a.ups_s > 0) {
-          const int co = row / a.ups_s, rr = row - co * a.ups_s;
-          const int n = a.ups_s * q + rr - a.ups_p;
-          if (n < 0 || n >= a.T_store) continue;
-          oidx = (size_t)co * a.o_cs + n;
-        } else {
-          oidx = (size_t)row * a.o_cs + q;
-        }
-        if (resb) v += resb[(size_t)row * a.r_cs + q];
-        if (a.acc_prev) v += outb[oidx];
+        if (resb) v += rv[r];
+        if (a.acc_prev) v += pv[r];
         if (a.div != 1.f) v /= a.div;
         if (a.mask_post && !valid) v = 0.f;
-        outb[oidx] = v;
+        outb[oidx[r]] = v;
       }
     }
   }
@@ -236,7 +284,7 @@ static hipError_t launch_tile(const ConvArgs& a, int B, hipStream_t s) {
 }
 
 hipError_t launch_conv(const ConvArgs& a, int B, hipStream_t s) {
-  if ((a.K - 1) * a.dil > CONV_HALO || a.K < 1 || a.Nq <= 0 || B <= 0) return hipErrorInvalidValue;
+  if ((a.K - 1) * a.dil + 3 > CONV_HALO || a.K < 1 || a.Nq <= 0 || B <= 0) return hipErrorInvalidValue;
   const bool gate = a.act == 2;
   if (a.M <= 32 && !gate) {
     if (a.Nq >= 1024) return launch_tile<1, 4, 1, 4>(a, B, s);

@@ -265,7 +265,7 @@ int plan_model(vsp_ctx* ctx) {
       rb.k = c.resblock_kernel_sizes[j];
       for (int q = 0; q < c.n_resblock_dilations; ++q) {
         const int d = c.resblock_dilation_sizes[j][q];
-        if ((rb.k - 1) * d > CONV_HALO) return ctx->fail(VSP_ERR_UNSUPPORTED, "resblock halo (k-1)*d > %d", CONV_HALO);
+        if ((rb.k - 1) * d + 3 > CONV_HALO) return ctx->fail(VSP_ERR_UNSUPPORTED, "resblock halo (k-1)*d > %d", CONV_HALO);
         rb.dil.push_back(d);
         rb.c1.push_back(p.conv(ch, ch, rb.k, d, (rb.k * d - d) / 2, true));
         rb.c2.push_back(p.conv(ch, ch, rb.k, 1, (rb.k - 1) / 2, true));
