@@ -162,12 +162,14 @@ int vsp_rq_spline(void* stream, int64_t n, int nb, const float* x, const float* 
                   const float* ud, int inverse, float tail_bound, float* y, float* logabsdet);
 
 /* ---- measurement -------------------------------------------------------------------------- */
-/* When enabled, every launch of the dominant kernel (the MFMA implicit-GEMM conv) inside the
- * generator is bracketed by a HIP event pair on the launch stream.  vsp_profile_read synchronises
- * those events and returns, since the last reset: the number of launches, their summed duration
- * in milliseconds, and their summed algorithmic FLOPs (2 * rows * Cin * taps * columns * B). */
+/* When enabled, every launch of the dominant kernel (the generator's MFMA convolution) is
+ * bracketed by a HIP event pair on the launch stream.  vsp_profile_read synchronises those events
+ * and returns, since the last reset: the number of launches, their summed duration in
+ * milliseconds, their summed algorithmic FLOPs (2 * Cout * Cin * taps * columns * B) and their
+ * summed algorithmic bytes (input once + output once + residual / accumulate reads, fp32). */
 int vsp_profile_enable(vsp_ctx* ctx, int on);
-int vsp_profile_read(vsp_ctx* ctx, int64_t* launches, double* total_ms, double* total_flops, int reset);
+int vsp_profile_read(vsp_ctx* ctx, int64_t* launches, double* total_ms, double* total_flops, double* total_bytes,
+                     int reset);
 
 #ifdef __cplusplus
 }

@@ -72,7 +72,7 @@ def test_arena_and_workspace_sizes(ctx):
     arena = lib.vsp_weight_arena_bytes(h)
     n_params = sum(int(np.prod(s)) for s in infer_schema(ModelDims()).values())
     # packed arena holds every infer-path parameter (weight_g folded away, some zero padding)
-    assert 0.9 * 4 * n_params < arena < 1.3 * 4 * n_params
+    assert 0.9 * 4 * n_params < arena < 1.5 * 4 * n_params   # generator weights are held in both packings
     e1, e2 = lib.vsp_encode_workspace_bytes(h, 2, 40), lib.vsp_encode_workspace_bytes(h, 4, 40)
     assert 0 < e1 < e2
     d1, d2 = lib.vsp_decode_workspace_bytes(h, 1, 40, 100), lib.vsp_decode_workspace_bytes(h, 1, 40, 200)

@@ -241,3 +241,20 @@ def test_valid_region_properties(net):
     assert (m_p * (1 - m)).abs().max() == 0 and (logs_p * (1 - m)).abs().max() == 0
     assert x_mask.sum(dim=(1, 2)).cpu().tolist() == batch["frame_lengths"].tolist()
     assert o.shape[-1] == 512 * int(batch["frame_lengths"].max())
+
+
+def test_f32_generator_mode_matches_golden(dims, weights, golden_dir, monkeypatch):
+    """The f32-MFMA channel-major generator (VSP_GENERATOR=f32) stays available as a second,
+    independently written implementation of Generator.forward; both must match the reference."""
+    monkeypatch.setenv("VSP_GENERATOR", "f32")
+    from vispeech_amd import config as vcfg
+    from vispeech_amd.models import SynthesizerTrn
+    args, kwargs = vcfg.synthesizer_args(vcfg.default_hparams())
+    m = SynthesizerTrn(*args, **kwargs).eval()
+    m.load_state_dict(weights, strict=True)
+    for case in ("ragged_controls", "maxlen_dur3d"):
+        g = golden(golden_dir, case)
+        o = run_case(m, g)[0]
+        e = rel_err(to_np(o), g["o"])
+        print("f32 generator", case, f"{e:.2e}")
+        assert e <= WAVE_TOL

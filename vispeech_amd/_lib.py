@@ -66,7 +66,7 @@ SIGNATURES = {
     "vsp_generator": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _I64]),
     "vsp_rq_spline": (_I, [_P, _I64, _I, _P, _P, _P, _P, _I, _F, _P, _P]),
     "vsp_profile_enable": (_I, [_P, _I]),
-    "vsp_profile_read": (_I, [_P, C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double), _I]),
+    "vsp_profile_read": (_I, [_P, C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), _I]),
 }
 
 _lib: Optional[C.CDLL] = None

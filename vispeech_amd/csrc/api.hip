@@ -4,6 +4,7 @@
 // vsp_frame_lengths_host.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "model.h"
@@ -90,6 +91,46 @@ struct Run {
       (void)hipEventRecord(e1, s);
       ctx->prof_launches += 1;
       ctx->prof_flops += 2.0 * a.M * a.Cin * a.K * (double)a.Nq * B;
+      const double in_el = (double)a.T_in * a.Cin, out_el = (double)(a.ups_s > 0 ? a.T_store * (a.M / a.ups_s) : a.Nq * a.M);
+      ctx->prof_bytes += 4.0 * B * (in_el + out_el * (1.0 + (a.res ? 1.0 : 0.0) + (a.acc_prev ? 1.0 : 0.0)));
+    }
+  }
+  // channels-last split-f16 conv: x [B][T_in][Cin] -> out rows of Cout
+  void clconv(const ClConv& L, const float* x, long x_bs, float* out, long o_bs, const float* res, long r_bs, int T_in,
+              int Nq, int T_store, float in_slope, bool acc_prev, float div, int B) {
+    if (dry() || !ok()) return;
+    ClConvArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.x = x; a.x_bs = x_bs; a.x_ts = L.Cin;
+    a.wh = reinterpret_cast<const uint16_t*>(A(L.wh));
+    a.wl = reinterpret_cast<const uint16_t*>(A(L.wl));
+    a.bias = A((size_t)L.b);
+    a.out = out; a.o_bs = o_bs; a.o_ts = L.Cout;
+    a.res = res; a.r_bs = r_bs; a.r_ts = L.Cout;
+    a.Cin = L.Cin; a.Cout = L.Cout; a.K = L.K; a.dil = L.dil; a.pad = L.pad;
+    a.T_in = T_in; a.Nq = Nq;
+    a.in_act = 1; a.in_slope = in_slope;
+    a.acc_prev = acc_prev ? 1 : 0; a.div = div;
+    a.phases = L.phases; a.ups_p = L.ups_p; a.T_store = T_store;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->prof_on) {
+      while (ctx->ev_pool.size() < ctx->ev_used + 2) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) { rc = ctx->fail(VSP_ERR_HIP, "hipEventCreate"); return; }
+        ctx->ev_pool.push_back(e);
+      }
+      e0 = ctx->ev_pool[ctx->ev_used++];
+      e1 = ctx->ev_pool[ctx->ev_used++];
+      (void)hipEventRecord(e0, s);
+    }
+    chk(launch_cl_conv(a, B, s), "cl_conv_f16s");
+    if (e1) {
+      (void)hipEventRecord(e1, s);
+      ctx->prof_launches += 1;
+      ctx->prof_flops += 2.0 * L.Cout * L.Cin * L.K * L.phases * (double)Nq * B;
+      // algorithmic bytes: input once, output once, plus the residual / accumulate reads
+      const double in_el = (double)T_in * L.Cin, out_el = (double)T_store * L.Cout;
+      ctx->prof_bytes += 4.0 * B * (in_el + out_el * (1.0 + (res ? 1.0 : 0.0) + (acc_prev ? 1.0 : 0.0)));
     }
   }
   // cond(g): 1x1 conv on g [B][gin] (T = 1) -> out [B][M]
@@ -272,6 +313,68 @@ void run_generator(Run& r, int B, int T, T3 z, const int64_t* in_lengths, const 
           "conv_post");
 }
 
+// Generator.forward on the split-f16 channels-last kernels (conv_f16s.hip): conv_pre stays on the
+// f32 kernel (input z is channel-major and tiny), its output is transposed once to [B][T][C].
+void run_generator_cl(Run& r, int B, int T, T3 z, const int64_t* in_lengths, const float* g, float* o) {
+  const vsp_config& c = r.ctx->cfg;
+  const Model& m = r.ctx->model;
+  const int c0 = c.upsample_initial_channel, nk = c.n_resblock_kernels;
+  float* gc = r.ws.f((size_t)B * c0);
+  r.cond(m.g_cond, g, gc, B);
+  T3 X0 = r.ws.t3(B, c0, T);
+  size_t mx = (size_t)c0 * T;
+  {
+    long t = T;
+    for (int i = 0; i < c.n_upsamples; ++i) {
+      t *= c.upsample_rates[i];
+      mx = std::max(mx, (size_t)(c0 >> (i + 1)) * (size_t)t);
+    }
+  }
+  float* buf[5];
+  for (auto& bptr : buf) bptr = r.ws.f((size_t)B * mx);
+  ConvArgs a = r.args(m.g_pre, z, X0, T, T);
+  a.lengths = in_lengths; a.in_mask = in_lengths ? 1 : 0;
+  a.cond = gc; a.cond_bs = c0;
+  r.conv(a, B, true);
+  int cur = 0;
+  if (!r.dry() && r.ok())
+    r.chk(launch_transpose_ct(X0.p, X0.bs, X0.cs, buf[cur], (long)T * c0, c0, B, c0, T, r.s), "transpose");
+  long Tn = T;
+  int ch = c0;
+  for (int i = 0; i < c.n_upsamples; ++i) {
+    const ClConv& U = m.ups_h[i];
+    const long Tout = Tn * U.phases;
+    const int cin = ch;
+    ch = c0 >> (i + 1);
+    int fb[4], nf = 0;
+    for (int k = 0; k < 5; ++k) if (k != cur) fb[nf++] = k;
+    float *XU = buf[fb[0]], *T1 = buf[fb[1]], *YA = buf[fb[2]], *XS = buf[fb[3]];
+    const long bs = Tout * ch;
+    r.clconv(U, buf[cur], Tn * cin, XU, bs, nullptr, 0, (int)Tn, (int)Tn + 1, (int)Tout, 0.1f, false, 1.f, B);
+    for (int j = 0; j < nk; ++j) {
+      const ResBlockW& rb = m.rbs[i * nk + j];
+      const int nd = (int)rb.dil.size();
+      for (int d = 0; d < nd; ++d) {
+        const float* yin = d == 0 ? XU : YA;
+        r.clconv(rb.h1[d], yin, bs, T1, bs, nullptr, 0, (int)Tout, (int)Tout, (int)Tout, 0.1f, false, 1.f, B);
+        const bool last = d == nd - 1;
+        r.clconv(rb.h2[d], T1, bs, last ? XS : YA, bs, yin, bs, (int)Tout, (int)Tout, (int)Tout, 0.1f, last && j > 0,
+                 (last && j == nk - 1) ? (float)nk : 1.f, B);
+      }
+    }
+    cur = fb[3];
+    Tn = Tout;
+  }
+  if (!r.dry() && r.ok())
+    r.chk(launch_conv_post_cl(buf[cur], Tn * ch, ch, r.A(m.post_w), m.post_c, m.post_k, 0.01f, o, Tn, B, (int)Tn, r.s),
+          "conv_post_cl");
+}
+
+void run_gen(Run& r, int B, int T, T3 z, const int64_t* in_lengths, const float* g, float* o) {
+  if (r.ctx->gen_mode == 1 && r.ctx->model.has_cl) run_generator_cl(r, B, T, z, in_lengths, g, o);
+  else run_generator(r, B, T, z, in_lengths, g, o);
+}
+
 int check_ready(vsp_ctx* ctx) {
   if (!ctx) return VSP_ERR_ARG;
   if (!ctx->ready) return ctx->fail(VSP_ERR_STATE, "weights not finalised");
@@ -299,6 +402,9 @@ int vsp_create(const vsp_config* cfg, int device, vsp_ctx** out) {
   ctx->device = device;
   build_schema(ctx->cfg, ctx->schema);
   const int rc = plan_model(ctx);
+  if (const char* e = getenv("VSP_GENERATOR")) {
+    if (!strcmp(e, "f32")) ctx->gen_mode = 0;
+  }
   *out = ctx;  // returned even on failure so that vsp_last_error can be read; caller destroys it
   return rc;
 }
@@ -556,7 +662,7 @@ static int decode_impl(vsp_ctx* ctx, hipStream_t s, Ws& ws, int B, int Tp, int T
   }
   run_flow(r, B, Tf, Z, g, frame_lengths);
   const int Tdec = max_len < 0 ? Tf : std::min(Tf, max_len);
-  if (Tdec > 0) run_generator(r, B, Tdec, Z, frame_lengths, g, o);
+  if (Tdec > 0) run_gen(r, B, Tdec, Z, frame_lengths, g, o);
   if (ws.overflow) return ctx->fail(VSP_ERR_WORKSPACE, "decode workspace too small (need %zu bytes)", ws.cur);
   return r.rc;
 }
@@ -649,7 +755,7 @@ int64_t vsp_generator_workspace_bytes(const vsp_ctx* ctx, int B, int T) {
   if (!ctx || B <= 0 || T <= 0) return VSP_ERR_ARG;
   Ws ws(nullptr, 0, true);
   Run r{const_cast<vsp_ctx*>(ctx), nullptr, ws};
-  run_generator(r, B, T, T3{}, nullptr, nullptr, nullptr);
+  run_gen(r, B, T, T3{}, nullptr, nullptr, nullptr);
   return (int64_t)ws.cur;
 }
 
@@ -660,7 +766,7 @@ int vsp_generator(vsp_ctx* ctx, void* stream, int B, int T, const float* z, cons
   if (B <= 0 || T <= 0 || !z || !g || !o || !workspace) return ctx->fail(VSP_ERR_ARG, "vsp_generator: bad argument");
   Ws ws(workspace, (size_t)workspace_bytes, false);
   Run r{ctx, (hipStream_t)stream, ws};
-  run_generator(r, B, T, ext(z, ctx->cfg.inter_channels, T), nullptr, g, o);
+  run_gen(r, B, T, ext(z, ctx->cfg.inter_channels, T), nullptr, g, o);
   if (ws.overflow) return ctx->fail(VSP_ERR_WORKSPACE, "generator workspace too small (need %zu bytes)", ws.cur);
   return r.rc;
 }
@@ -679,8 +785,9 @@ int vsp_profile_enable(vsp_ctx* ctx, int on) {
   return VSP_OK;
 }
 
-int vsp_profile_read(vsp_ctx* ctx, int64_t* launches, double* total_ms, double* total_flops, int reset) {
-  if (!ctx || !launches || !total_ms || !total_flops) return VSP_ERR_ARG;
+int vsp_profile_read(vsp_ctx* ctx, int64_t* launches, double* total_ms, double* total_flops, double* total_bytes,
+                     int reset) {
+  if (!ctx || !launches || !total_ms || !total_flops || !total_bytes) return VSP_ERR_ARG;
   double ms = 0.0;
   for (size_t i = 0; i + 1 < ctx->ev_used; i += 2) {
     hipError_t e = hipEventSynchronize(ctx->ev_pool[i + 1]);
@@ -692,10 +799,12 @@ int vsp_profile_read(vsp_ctx* ctx, int64_t* launches, double* total_ms, double* 
   *launches = ctx->prof_launches;
   *total_ms = ms;
   *total_flops = ctx->prof_flops;
+  *total_bytes = ctx->prof_bytes;
   if (reset) {
     ctx->ev_used = 0;
     ctx->prof_launches = 0;
     ctx->prof_flops = 0.0;
+    ctx->prof_bytes = 0.0;
   }
   return VSP_OK;
 }

@@ -1,0 +1,308 @@
+// Vocoder convolution on the f16 matrix core with SPLIT operands -- fp32-accurate at ~4.6x the
+// native f32 MFMA rate (measured on MI355X, profiles/r01_exp_split_f16.log: v_mfma_f32_32x32x16_f16
+// 2.06 PFLOP/s vs v_mfma_f32_32x32x2_f32 0.148; error of the 3-term split 6e-8 * sum|ab|, i.e. no
+// worse than an f32 fmaf chain).
+//
+//   x = xh + xl * 2^-11,  xh = f16(x),  xl = f16((x - xh) * 2^11)      (exact residual, scaled so the
+//   w = wh + wl * 2^-11                                                  low part never underflows)
+//   x*w ~= xh*wh + (xh*wl + xl*wh) * 2^-11        (dropped xl*wl term <= 2^-24 |x w|)
+//   -> two f32 accumulators per output tile: HH and CROSS; result = HH + CROSS * 2^-11.
+//
+// Layout: the vocoder's activations live CHANNELS-LAST in HBM, [B][T][C] fp32, so that
+//   * a block's input window (rows t0-pad .. t0+BT+halo, one ci chunk) is read with 16-byte loads
+//     that cover whole 128/256-byte rows (perfectly coalesced), activated (leaky-relu), split and
+//     written once to LDS as two f16 images [row][CKC+8] (row stride 80/144 B: conflict-free
+//     ds_read_b128 for the A fragments: lane = time row, 8 consecutive input channels);
+//   * GEMM orientation M = time, N = output channel, K = (tap, ci): the D tile has the output
+//     channel on the lane, so every store instruction writes two full contiguous rows;
+//   * weights are pre-split and pre-packed on the host in B-fragment order ([phase][tap][k-step]
+//     [n-tile][lane][8 f16]); a wave fetches a fragment with one 1 KiB global_load_dwordx4 (L2).
+// ConvTranspose1d runs as `phases` = stride independent polyphase GEMMs (blockIdx.y), each writing
+// rows n = s*q + r - p, which are again whole contiguous rows.
+//
+// Reference call sites: modules.py:210-223 (ResBlock1 convs), models.py:255-257, 276-285 (ups,
+// resblock averaging).
+#include "kernels.h"
+
+#include <cstring>
+
+namespace vsp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CL_HALO = 64;  // max (K-1)*dil
+
+size_t packed_cl_halfs(int Cout, int Cin, int K, int phases) {
+  return (size_t)phases * K * (Cin / 16) * (Cout / 32) * 64 * 8;
+}
+
+// dense: W[phase][co][ci][tap] fp32 -> hi / lo f16 fragment images (each packed_cl_halfs halfs)
+void pack_cl_weights(uint16_t* hi, uint16_t* lo, int Cout, int Cin, int K, int phases, const float* dense) {
+  const int nks = Cin / 16, nnt = Cout / 32;
+  for (int ph = 0; ph < phases; ++ph)
+    for (int co = 0; co < Cout; ++co)
+      for (int ci = 0; ci < Cin; ++ci)
+        for (int tap = 0; tap < K; ++tap) {
+          const float w = dense[(((size_t)ph * Cout + co) * Cin + ci) * K + tap];
+          const _Float16 h = (_Float16)w;
+          const _Float16 l = (_Float16)((w - (float)h) * 2048.f);
+          const int ks = ci / 16, hh = (ci % 16) / 8, j = ci % 8, nt = co / 32, lane = (co % 32) + 32 * hh;
+          const size_t idx = (((((size_t)ph * K + tap) * nks + ks) * nnt + nt) * 64 + lane) * 8 + j;
+          std::memcpy(hi + idx, &h, 2);
+          std::memcpy(lo + idx, &l, 2);
+        }
+}
+
+template <int MT, int NT, int WM, int WN, int CKC>
+__global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
+  constexpr int BT = 32 * MT * WM;
+  constexpr int RS = CKC + 8;           // LDS row stride (halfs): 80 B / 144 B
+  constexpr int NTH = 64 * WM * WN;
+  constexpr int WMAX = BT + CL_HALO;
+  constexpr int C4 = CKC / 4;           // float4 per staged row
+  constexpr int U = 8;                  // loads in flight per thread while staging
+  extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+  _Float16* Xh = lds;
+  _Float16* Xl = lds + WMAX * RS;
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int b = blockIdx.z;
+  const int t0 = blockIdx.x * BT;
+  const int nnt = a.Cout >> 5, nks = a.Cin >> 4;
+  const int ncb = (nnt + NT * WN - 1) / (NT * WN);       // co blocks
+  const int ph = blockIdx.y / ncb, cb = blockIdx.y - ph * ncb;
+  const int ntile0 = (cb * WN + wn) * NT;
+  const int row0 = wm * MT * 32;
+  const int W = BT + (a.K - 1) * a.dil;
+  const int nchunks = a.Cin / CKC;
+
+  f32x16 hh[MT][NT], cr[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { hh[mt][nt][r] = 0.f; cr[mt][nt][r] = 0.f; }
+
+  const f16x8* WH = reinterpret_cast<const f16x8*>(a.wh);
+  const f16x8* WL = reinterpret_cast<const f16x8*>(a.wl);
+  const float* xb = a.x + (size_t)b * a.x_bs;
+
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    if (chunk > 0) __syncthreads();
+    // ---- stage: global fp32 (channels-last) -> leaky-relu -> split -> LDS f16 hi / lo
+    const int total4 = W * C4;
+    for (int i0 = 0; i0 < total4; i0 += NTH * U) {
+      float4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int idx = i0 + u * NTH + tid;
+        const int row = idx / C4, c4 = idx % C4;
+        const int t = t0 - a.pad + row;
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < total4 && t >= 0 && t < a.T_in)
+          v[u] = *reinterpret_cast<const float4*>(xb + (size_t)t * a.x_ts + chunk * CKC + 4 * c4);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int idx = i0 + u * NTH + tid;
+        if (idx >= total4) continue;
+        const int row = idx / C4, c4 = idx % C4;
+        float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+        f16x4 eh, el;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float x = e[k];
+          if (a.in_act) x = x > 0.f ? x : x * a.in_slope;
+          const _Float16 xh = (_Float16)x;
+          eh[k] = xh;
+          el[k] = (_Float16)((x - (float)xh) * 2048.f);
+        }
+        *reinterpret_cast<f16x4*>(Xh + row * RS + 4 * c4) = eh;
+        *reinterpret_cast<f16x4*>(Xl + row * RS + 4 * c4) = el;
+      }
+    }
+    __syncthreads();
+    // ---- MFMA: per (tap, k-step) NT weight fragments (global, L2) x MT activation fragments (LDS)
+    for (int tap = 0; tap < a.K; ++tap) {
+      const int rbase = row0 + l31 + tap * a.dil;
+#pragma unroll
+      for (int ks = 0; ks < CKC / 16; ++ks) {
+        const int gks = chunk * (CKC / 16) + ks;
+        f16x8 wh[NT], wl[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int ntile = ntile0 + nt;
+          if (ntile < nnt) {
+            const size_t widx = ((((size_t)ph * a.K + tap) * nks + gks) * nnt + ntile) * 64 + lane;
+            wh[nt] = WH[widx];
+            wl[nt] = WL[widx];
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { wh[nt][j] = (_Float16)0.f; wl[nt][j] = (_Float16)0.f; }
+          }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int off = (rbase + mt * 32) * RS + ks * 16 + 8 * h;
+          const f16x8 xh = *reinterpret_cast<const f16x8*>(Xh + off);
+          const f16x8 xl = *reinterpret_cast<const f16x8*>(Xl + off);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            hh[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh[nt], hh[mt][nt], 0, 0, 0);
+            cr[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wl[nt], cr[mt][nt], 0, 0, 0);
+            cr[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wh[nt], cr[mt][nt], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: rows = time (registers), lane = output channel -> contiguous 128-byte rows
+  float* outb = a.out + (size_t)b * a.o_bs;
+  const float* resb = a.res ? a.res + (size_t)b * a.r_bs : nullptr;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int ntile = ntile0 + nt;
+      if (ntile >= nnt) continue;
+      const int co = ntile * 32 + l31;
+      const float bias = a.bias ? a.bias[co] : 0.f;
+      bool st[16];
+      size_t oidx[16];
+      float rv[16], pv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = t0 + row0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int n = a.phases > 1 ? a.phases * q + ph - a.ups_p : q;
+        st[r] = q < a.Nq && n >= 0 && n < a.T_store;
+        oidx[r] = (size_t)n * a.o_ts + co;
+        rv[r] = (resb && st[r]) ? resb[(size_t)n * a.r_ts + co] : 0.f;
+        pv[r] = (a.acc_prev && st[r]) ? outb[oidx[r]] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (!st[r]) continue;
+        float v = hh[mt][nt][r] + cr[mt][nt][r] * (1.f / 2048.f) + bias;
+        if (resb) v += rv[r];
+        if (a.acc_prev) v += pv[r];
+        if (a.div != 1.f) v /= a.div;
+        outb[oidx[r]] = v;
+      }
+    }
+  }
+}
+
+template <int MT, int NT, int WM, int WN, int CKC>
+static hipError_t launch_cl_tile(const ClConvArgs& a, int B, hipStream_t s) {
+  constexpr int BT = 32 * MT * WM;
+  constexpr size_t lds = (size_t)2 * (BT + CL_HALO) * (CKC + 8) * sizeof(_Float16);
+  static bool attr_set = false;
+  auto kern = cl_conv_f16s<MT, NT, WM, WN, CKC>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int nnt = a.Cout / 32, ncb = (nnt + NT * WN - 1) / (NT * WN);
+  dim3 grid((a.Nq + BT - 1) / BT, a.phases * ncb, B);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_cl_conv(const ClConvArgs& a, int B, hipStream_t s) {
+  if ((a.K - 1) * a.dil > CL_HALO || a.K < 1 || a.Nq <= 0 || B <= 0 || a.Cout % 32 || a.Cin % 32 || a.phases < 1 ||
+      (a.x_ts & 3) || (a.x_bs & 3) || (reinterpret_cast<uintptr_t>(a.x) & 15))
+    return hipErrorInvalidValue;
+  if (a.Cin == 32) {
+    if (a.Cout != 32) return hipErrorInvalidValue;
+    return launch_cl_tile<2, 1, 4, 1, 32>(a, B, s);
+  }
+  if (a.Cin % 64) return hipErrorInvalidValue;
+  if (a.Cout == 32) return launch_cl_tile<1, 1, 4, 1, 64>(a, B, s);
+  if (a.Cout == 64) return launch_cl_tile<1, 2, 4, 1, 64>(a, B, s);
+  if (a.Cout % 128 == 0) return launch_cl_tile<2, 2, 2, 2, 64>(a, B, s);
+  return launch_cl_tile<1, 2, 4, 1, 64>(a, B, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// [B][C][T] -> [B][T][C] (conv_pre's output enters the channels-last vocoder), 32x32 LDS tiles
+__global__ void __launch_bounds__(256) transpose_ct_kernel(const float* __restrict__ x, long x_bs, long x_cs,
+                                                           float* __restrict__ y, long y_bs, int y_ts, int C, int T) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, c0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + ly + 8 * k, t = t0 + lx;
+    tile[ly + 8 * k][lx] = (c < C && t < T) ? x[(size_t)b * x_bs + (size_t)c * x_cs + t] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int t = t0 + ly + 8 * k, c = c0 + lx;
+    if (t < T && c < C) y[(size_t)b * y_bs + (size_t)t * y_ts + c] = tile[lx][ly + 8 * k];
+  }
+}
+hipError_t launch_transpose_ct(const float* x, long x_bs, long x_cs, float* y, long y_bs, int y_ts, int B, int C,
+                               int T, hipStream_t s) {
+  hipLaunchKernelGGL(transpose_ct_kernel, dim3((T + 31) / 32, (C + 31) / 32, B), dim3(256), 0, s, x, x_bs, x_cs, y,
+                     y_bs, y_ts, C, T);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// conv_post on a channels-last input: o[b][t] = tanh(sum_j sum_c w[c][j] * lrelu(x[b][t+j-pad][c]))
+// (reference models.py:286-288).  Block = 256 outputs; the (256+K-1) x C window is one contiguous
+// chunk of HBM; LDS rows padded to C+1 floats (conflict-free column walks).
+constexpr int CPL_TILE = 256;
+__global__ void __launch_bounds__(256) conv_post_cl_kernel(const float* __restrict__ x, long x_bs, int x_ts,
+                                                           const float* __restrict__ w, int C, int K, float slope,
+                                                           float* __restrict__ o, long o_bs, int T) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int RSf = C + 1;
+  float* xs = sm;                             // [CPL_TILE + K - 1][C + 1]
+  float* ws = sm + (CPL_TILE + 8) * RSf;      // [K][C]  (tap-major for the inner loop)
+  const int b = blockIdx.y, t0 = blockIdx.x * CPL_TILE, pad = (K - 1) / 2;
+  const int rows = CPL_TILE + K - 1;
+  const float* xb = x + (size_t)b * x_bs;
+  for (int idx = threadIdx.x; idx < C * K; idx += 256) {
+    const int j = idx / C, c = idx % C;
+    ws[idx] = w[c * K + j];
+  }
+  for (int idx = threadIdx.x; idx < rows * C; idx += 256) {
+    const int row = idx / C, c = idx % C;
+    const int t = t0 - pad + row;
+    float v = 0.f;
+    if (t >= 0 && t < T) {
+      v = xb[(size_t)t * x_ts + c];
+      v = v > 0.f ? v : v * slope;
+    }
+    xs[row * RSf + c] = v;
+  }
+  __syncthreads();
+  const int t = t0 + threadIdx.x;
+  float acc = 0.f;
+  for (int c = 0; c < C; ++c) {
+#pragma unroll 7
+    for (int j = 0; j < K; ++j) acc += ws[j * C + c] * xs[(threadIdx.x + j) * RSf + c];
+  }
+  if (t < T) o[(size_t)b * o_bs + t] = tanhf(acc);
+}
+hipError_t launch_conv_post_cl(const float* x, long x_bs, int x_ts, const float* w, int C, int K, float slope,
+                               float* o, long o_bs, int B, int T, hipStream_t s) {
+  if (K > 8 || C > 64) return hipErrorInvalidValue;
+  const size_t lds = ((size_t)(CPL_TILE + 8) * (C + 1) + (size_t)K * C) * sizeof(float);
+  hipLaunchKernelGGL(conv_post_cl_kernel, dim3((T + CPL_TILE - 1) / CPL_TILE, B), dim3(256), lds, s, x, x_bs, x_ts,
+                     w, C, K, slope, o, o_bs, T);
+  return hipGetLastError();
+}
+
+}  // namespace vsp

@@ -45,6 +45,28 @@ size_t packed_conv_floats(int M, int Cin, int K);
 void pack_conv_weights(float* dst, int M, int Cin, int K, const float* dense /* [M][Cin][K] */);
 
 // ------------------------------------------------------------------------------------------
+// channels-last split-f16 vocoder conv (conv_f16s.hip): x [B][T][Cin], out [B][T][Cout]
+struct ClConvArgs {
+  const float* x; long x_bs; int x_ts;
+  const uint16_t* wh; const uint16_t* wl;   // packed f16 hi / lo fragments
+  const float* bias;                        // [Cout] or null
+  float* out; long o_bs; int o_ts;
+  const float* res; long r_bs; int r_ts;
+  int Cin, Cout, K, dil, pad;
+  int T_in, Nq;
+  int in_act; float in_slope;
+  int acc_prev; float div;
+  int phases, ups_p, T_store;               // polyphase transposed conv: row n = phases*q + ph - ups_p
+};
+hipError_t launch_cl_conv(const ClConvArgs& a, int B, hipStream_t s);
+size_t packed_cl_halfs(int Cout, int Cin, int K, int phases);
+void pack_cl_weights(uint16_t* hi, uint16_t* lo, int Cout, int Cin, int K, int phases, const float* dense);
+hipError_t launch_transpose_ct(const float* x, long x_bs, long x_cs, float* y, long y_bs, int y_ts, int B, int C,
+                               int T, hipStream_t s);
+hipError_t launch_conv_post_cl(const float* x, long x_bs, int x_ts, const float* w, int C, int K, float slope,
+                               float* o, long o_bs, int B, int T, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------
 // attention with windowed relative position (reference attentions.py:148-179), f32 MFMA.
 // qkv [B][3*H][T]: rows [0,H) = q, [H,2H) = k, [2H,3H) = v; out [B][H][T].
 hipError_t launch_attention(const float* qkv, long qkv_bs, long qkv_cs, const float* emb_k,

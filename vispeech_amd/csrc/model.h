@@ -27,6 +27,13 @@ struct Conv {
   long b = -1;
 };
 
+// One channels-last split-f16 conv (conv_f16s.hip); wh / wl offsets in floats (2 halfs per float).
+struct ClConv {
+  int Cout = 0, Cin = 0, K = 1, dil = 1, pad = 0, phases = 1, ups_p = 0;
+  size_t wh = 0, wl = 0;
+  long b = -1;
+};
+
 struct EncLayer {
   Conv qkv, o, f1, f2;
   size_t ek = 0, ev = 0, g1 = 0, b1 = 0, g2 = 0, b2 = 0;
@@ -43,7 +50,8 @@ struct FlowW {
 struct ResBlockW {
   int k = 0;
   std::vector<int> dil;
-  std::vector<Conv> c1, c2;
+  std::vector<Conv> c1, c2;        // f32-MFMA packing (generator mode 0)
+  std::vector<ClConv> h1, h2;      // split-f16 packing (generator mode 1)
 };
 
 struct Model {
@@ -60,10 +68,12 @@ struct Model {
   std::vector<FlowW> flows;  // index = flow layer i (applied in order n_flows-1 .. 0)
   Conv g_pre, g_cond;
   std::vector<Conv> ups;
+  std::vector<ClConv> ups_h;
   std::vector<ResBlockW> rbs;
   size_t post_w = 0;
   int post_k = 7, post_c = 32;
   size_t total_floats = 0;
+  bool has_cl = false;  // split-f16 channels-last generator weights present
 };
 
 struct SchemaEntry {
@@ -83,12 +93,14 @@ struct vsp_ctx {
   float* arena = nullptr;
   bool arena_owned = false;
   bool ready = false;
+  int gen_mode = 1;  // 0: f32 MFMA channel-major generator, 1: split-f16 MFMA channels-last generator
   // profiling of the dominant kernel
   bool prof_on = false;
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
   int64_t prof_launches = 0;
   double prof_flops = 0.0;
+  double prof_bytes = 0.0;
 
   int fail(int code, const char* fmt, ...) {
     char buf[512];

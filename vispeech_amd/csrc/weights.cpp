@@ -165,6 +165,15 @@ struct Planner {
     c.b = bias ? (long)raw((size_t)M) : -1;
     return c;
   }
+  ClConv clconv(int Cout, int Cin, int K, int dil, int pad, int phases, int ups_p) {
+    ClConv c;
+    c.Cout = Cout; c.Cin = Cin; c.K = K; c.dil = dil; c.pad = pad; c.phases = phases; c.ups_p = ups_p;
+    const size_t halfs = packed_cl_halfs(Cout, Cin, K, phases);
+    c.wh = raw(halfs / 2);
+    c.wl = raw(halfs / 2);
+    c.b = (long)raw((size_t)Cout);
+    return c;
+  }
 };
 
 static void plan_encoder(Planner& p, EncoderW& e, const std::string& prefix, int n_layers, const vsp_config& c) {
@@ -249,6 +258,14 @@ int plan_model(vsp_ctx* ctx) {
   m.g_pre = p.conv(c0, inter, 7, 1, 3, true);
   m.g_cond = p.conv(c0, gin, 1, 1, 0, true);
   int ch = c0;
+  // the split-f16 channels-last generator covers channel counts of 32 or multiples of 64
+  m.has_cl = true;
+  for (int i = 0; i < c.n_upsamples; ++i) {
+    const int cin = c0 >> i, cout = c0 >> (i + 1);
+    if (cin % 32 || cout % 32 || (cin != 32 && cin % 64) || (cout != 32 && cout % 64)) m.has_cl = false;
+  }
+  if ((c0 >> c.n_upsamples) > 64) m.has_cl = false;  // conv_post_cl covers <= 64 channels
+  if (!m.has_cl) ctx->gen_mode = 0;
   for (int i = 0; i < c.n_upsamples; ++i) {
     const int s = c.upsample_rates[i], k = c.upsample_kernel_sizes[i];
     if (s < 1 || k % s || (k - s) % 2)
@@ -259,6 +276,8 @@ int plan_model(vsp_ctx* ctx) {
     u.ups_s = s;
     u.ups_p = (k - s) / 2;
     m.ups.push_back(u);
+    const bool cl_ok = m.has_cl;
+    if (cl_ok) m.ups_h.push_back(p.clconv(cout, cin, kt, 1, kt - 1, s, (k - s) / 2));
     ch = cout;
     for (int j = 0; j < c.n_resblock_kernels; ++j) {
       ResBlockW rb;
@@ -269,6 +288,10 @@ int plan_model(vsp_ctx* ctx) {
         rb.dil.push_back(d);
         rb.c1.push_back(p.conv(ch, ch, rb.k, d, (rb.k * d - d) / 2, true));
         rb.c2.push_back(p.conv(ch, ch, rb.k, 1, (rb.k - 1) / 2, true));
+        if (cl_ok) {
+          rb.h1.push_back(p.clconv(ch, ch, rb.k, d, (rb.k * d - d) / 2, 1, 0));
+          rb.h2.push_back(p.clconv(ch, ch, rb.k, 1, (rb.k - 1) / 2, 1, 0));
+        }
       }
       m.rbs.push_back(rb);
     }
@@ -331,6 +354,28 @@ struct Filler {
     pack_conv_weights(arena.data() + c.w, c.M, c.Cin, c.K, dense.data());
     if (c.b >= 0)
       for (int r = 0; r < c.M; ++r) arena[c.b + r] = b(r);
+  }
+  // channels-last split-f16 conv from an accessor W(phase, co, ci, tap)
+  void clconv(const ClConv& c, const std::function<float(int, int, int, int)>& w, const std::function<float(int)>& b) {
+    if (!ok) return;
+    std::vector<float> dense((size_t)c.phases * c.Cout * c.Cin * c.K);
+    for (int ph = 0; ph < c.phases; ++ph)
+      for (int co = 0; co < c.Cout; ++co)
+        for (int ci = 0; ci < c.Cin; ++ci)
+          for (int t = 0; t < c.K; ++t) dense[(((size_t)ph * c.Cout + co) * c.Cin + ci) * c.K + t] = w(ph, co, ci, t);
+    pack_cl_weights(reinterpret_cast<uint16_t*>(arena.data() + c.wh), reinterpret_cast<uint16_t*>(arena.data() + c.wl),
+                    c.Cout, c.Cin, c.K, c.phases, dense.data());
+    for (int co = 0; co < c.Cout; ++co) arena[c.b + co] = b(co);
+  }
+  void clconv_plain(const ClConv& c, const std::string& wname, const std::string& bname) {
+    const HostTensor* W = get(wname);
+    const HostTensor* B = get(bname);
+    if (!ok) return;
+    const float* wd = W->data.data();
+    const float* bd = B->data.data();
+    const int Cin = c.Cin, K = c.K;
+    clconv(c, [=](int, int co, int ci, int t) { return wd[((size_t)co * Cin + ci) * K + t]; },
+           [=](int co) { return bd[co]; });
   }
   // plain Conv1d weight [M][Cin][K] + bias, rows taken from [row0, row0+M)
   void conv_plain(const Conv& c, const std::string& wname, const std::string& bname, int row0 = 0) {
@@ -492,12 +537,22 @@ int fill_model(vsp_ctx* ctx, std::vector<float>& arena) {
       const int co = row / s, r = row % s, mm = kt - 1 - tap;
       return wd[((size_t)ci * cout + co) * k + s * mm + r];
     }, [=](int row) { return bd[row / s]; });
+    if (m.has_cl) {
+      // polyphase: out[s*q + r - p][co] = sum_m sum_ci x[q - m][ci] * w[ci][co][s*m + r], tap = kt-1-m
+      f.clconv(m.ups_h[i], [=](int r, int co, int ci, int tap) {
+        return wd[((size_t)ci * cout + co) * k + s * (kt - 1 - tap) + r];
+      }, [=](int co) { return bd[co]; });
+    }
     for (int j = 0; j < nk && f.ok; ++j) {
       const ResBlockW& rb = m.rbs[i * nk + j];
       const std::string q = "dec.resblocks." + std::to_string(i * nk + j);
       for (size_t d = 0; d < rb.dil.size(); ++d) {
         f.conv_plain(rb.c1[d], q + ".convs1." + std::to_string(d) + ".weight", q + ".convs1." + std::to_string(d) + ".bias");
         f.conv_plain(rb.c2[d], q + ".convs2." + std::to_string(d) + ".weight", q + ".convs2." + std::to_string(d) + ".bias");
+        if (m.has_cl) {
+          f.clconv_plain(rb.h1[d], q + ".convs1." + std::to_string(d) + ".weight", q + ".convs1." + std::to_string(d) + ".bias");
+          f.clconv_plain(rb.h2[d], q + ".convs2." + std::to_string(d) + ".weight", q + ".convs2." + std::to_string(d) + ".bias");
+        }
       }
     }
   }

@@ -227,10 +227,10 @@ class Engine:
         _lib.check(self.lib.vsp_profile_enable(self.ctx, int(on)), self.ctx, "vsp_profile_enable")
 
     def profile_read(self, reset: bool = True):
-        n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
-        _lib.check(self.lib.vsp_profile_read(self.ctx, C.byref(n), C.byref(ms), C.byref(fl), int(reset)), self.ctx,
-                   "vsp_profile_read")
-        return int(n.value), float(ms.value), float(fl.value)
+        n, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
+        _lib.check(self.lib.vsp_profile_read(self.ctx, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by), int(reset)),
+                   self.ctx, "vsp_profile_read")
+        return int(n.value), float(ms.value), float(fl.value), float(by.value)
 
 
 def rq_spline(x, uw, uh, ud, inverse: bool = False, tail_bound: float = 5.0):
