@@ -55,17 +55,28 @@ void pack_cl_weights(uint16_t* hi, uint16_t* lo, int Cout, int Cin, int K, int p
         }
 }
 
-template <int MT, int NT, int WM, int WN, int CKC>
+// Block = 8 waves, 256 time rows x (NT*WN*32) output channels.  Per ci-chunk the activated, split
+// input window sits in LDS (one buffer); the weights stream through a double-buffered LDS ring in
+// slices of G taps x one chunk (32 KiB hi+lo), fetched from L2 ONCE per block (register-staged one
+// slice ahead, so the fetch latency hides under the MFMAs of the current slice).  Every wave then
+// reads both operands' fragments from LDS (ds_read_b128, conflict-free) one k-step ahead of the
+// MFMAs that consume them.
+template <int MT, int NT, int WM, int WN, int CKC, int G, bool PF>
 __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
   constexpr int BT = 32 * MT * WM;
-  constexpr int RS = CKC + 8;           // LDS row stride (halfs): 80 B / 144 B
+  constexpr int RS = CKC + 8;                 // LDS row stride of the activation images (halfs)
   constexpr int NTH = 64 * WM * WN;
   constexpr int WMAX = BT + CL_HALO;
-  constexpr int C4 = CKC / 4;           // float4 per staged row
-  constexpr int U = 8;                  // loads in flight per thread while staging
+  constexpr int C4 = CKC / 4;                 // float4 per staged activation row
+  constexpr int NL = (WMAX * C4 + NTH - 1) / NTH;
+  constexpr int KS = CKC / 16;                // k-steps per tap and chunk
+  constexpr int NTB = NT * WN;                // 32-channel output tiles per block
+  constexpr int XIMG = WMAX * RS;             // halfs per activation image
+  constexpr int WIMG = G * KS * NTB * 64 * 8; // halfs per weight-slice image
+  constexpr int NWL = (2 * WIMG / 8 + NTH - 1) / NTH;   // 16-byte units per thread per slice (hi+lo)
   extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
-  _Float16* Xh = lds;
-  _Float16* Xl = lds + WMAX * RS;
+  _Float16* const Xh = lds;                   // [WMAX][RS] hi, then lo
+  _Float16* const Wb = lds + 2 * XIMG;        // 2 x (hi image, lo image)
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -74,12 +85,14 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
   const int b = blockIdx.z;
   const int t0 = blockIdx.x * BT;
   const int nnt = a.Cout >> 5, nks = a.Cin >> 4;
-  const int ncb = (nnt + NT * WN - 1) / (NT * WN);       // co blocks
+  const int ncb = nnt / NTB;
   const int ph = blockIdx.y / ncb, cb = blockIdx.y - ph * ncb;
-  const int ntile0 = (cb * WN + wn) * NT;
   const int row0 = wm * MT * 32;
   const int W = BT + (a.K - 1) * a.dil;
   const int nchunks = a.Cin / CKC;
+  const int total4 = W * C4;
+  const int ns = (a.K + G - 1) / G;           // weight slices per chunk
+  const int nsteps = nchunks * ns;
 
   f32x16 hh[MT][NT], cr[MT][NT];
 #pragma unroll
@@ -89,90 +102,151 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { hh[mt][nt][r] = 0.f; cr[mt][nt][r] = 0.f; }
 
-  const f16x8* WH = reinterpret_cast<const f16x8*>(a.wh);
-  const f16x8* WL = reinterpret_cast<const f16x8*>(a.wl);
   const float* xb = a.x + (size_t)b * a.x_bs;
+  const uint4* WHg = reinterpret_cast<const uint4*>(a.wh);
+  const uint4* WLg = reinterpret_cast<const uint4*>(a.wl);
 
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
-    if (chunk > 0) __syncthreads();
-    // ---- stage: global fp32 (channels-last) -> leaky-relu -> split -> LDS f16 hi / lo
-    const int total4 = W * C4;
-    for (int i0 = 0; i0 < total4; i0 += NTH * U) {
-      float4 v[U];
+  // ---- activation staging (issue early / convert + write late)
+  float4 sv[NL];
+  auto x_issue = [&](int chunk) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int idx = i0 + u * NTH + tid;
-        const int row = idx / C4, c4 = idx % C4;
-        const int t = t0 - a.pad + row;
-        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (idx < total4 && t >= 0 && t < a.T_in)
-          v[u] = *reinterpret_cast<const float4*>(xb + (size_t)t * a.x_ts + chunk * CKC + 4 * c4);
+    for (int u = 0; u < NL; ++u) {
+      const int idx = u * NTH + tid;
+      const int row = idx / C4, c4 = idx % C4;
+      const int t = t0 - a.pad + row;
+      sv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < total4 && t >= 0 && t < a.T_in)
+        sv[u] = *reinterpret_cast<const float4*>(xb + (size_t)t * a.x_ts + chunk * CKC + 4 * c4);
+    }
+  };
+  auto x_write = [&]() {
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+      const int idx = u * NTH + tid;
+      if (idx >= total4) continue;
+      const int row = idx / C4, c4 = idx % C4;
+      float e[4] = {sv[u].x, sv[u].y, sv[u].z, sv[u].w};
+      f16x4 eh, el;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float x = e[k];
+        if (a.in_act) x = x > 0.f ? x : x * a.in_slope;
+        const _Float16 xh = (_Float16)x;
+        eh[k] = xh;
+        el[k] = (_Float16)((x - (float)xh) * 2048.f);
       }
+      *reinterpret_cast<f16x4*>(Xh + row * RS + 4 * c4) = eh;
+      *reinterpret_cast<f16x4*>(Xh + XIMG + row * RS + 4 * c4) = el;
+    }
+  };
+  // ---- weight-slice staging: slice (chunk, sl) = taps [sl*G, sl*G+G) x k-steps of the chunk x the
+  //      block's NTB output tiles; 16-byte units, unit index = ((g*KS + ks)*NTB + ntl)*64 + lane
+  uint4 wv[NWL];
+  auto w_issue = [&](int step) {
+    const int chunk = step / ns, sl = step - chunk * ns;
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int idx = i0 + u * NTH + tid;
-        if (idx >= total4) continue;
-        const int row = idx / C4, c4 = idx % C4;
-        float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-        f16x4 eh, el;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          float x = e[k];
-          if (a.in_act) x = x > 0.f ? x : x * a.in_slope;
-          const _Float16 xh = (_Float16)x;
-          eh[k] = xh;
-          el[k] = (_Float16)((x - (float)xh) * 2048.f);
-        }
-        *reinterpret_cast<f16x4*>(Xh + row * RS + 4 * c4) = eh;
-        *reinterpret_cast<f16x4*>(Xl + row * RS + 4 * c4) = el;
+    for (int u = 0; u < NWL; ++u) {
+      const int idx = u * NTH + tid;
+      const int img = idx / (WIMG / 8), un = idx % (WIMG / 8);
+      const int ln = un % 64, ntl = (un / 64) % NTB, ks = (un / (64 * NTB)) % KS, g = un / (64 * NTB * KS);
+      const int tap = sl * G + g;
+      wv[u] = make_uint4(0u, 0u, 0u, 0u);
+      if (img < 2 && tap < a.K) {
+        const size_t src = ((((size_t)ph * a.K + tap) * nks + chunk * KS + ks) * nnt + cb * NTB + ntl) * 64 + ln;
+        wv[u] = img == 0 ? WHg[src] : WLg[src];
       }
     }
-    __syncthreads();
-    // ---- MFMA: per (tap, k-step) NT weight fragments (global, L2) x MT activation fragments (LDS)
-    for (int tap = 0; tap < a.K; ++tap) {
-      const int rbase = row0 + l31 + tap * a.dil;
+  };
+  auto w_write = [&](int buf) {
+    uint4* dst = reinterpret_cast<uint4*>(Wb + buf * 2 * WIMG);
 #pragma unroll
-      for (int ks = 0; ks < CKC / 16; ++ks) {
-        const int gks = chunk * (CKC / 16) + ks;
-        f16x8 wh[NT], wl[NT];
+    for (int u = 0; u < NWL; ++u) {
+      const int idx = u * NTH + tid;
+      if (idx < 2 * WIMG / 8) dst[idx] = wv[u];
+    }
+  };
+
+  // ---- fragment loads (LDS) and the 3-term product
+  auto load_frags = [&](const _Float16* Wc, int tap0, int it, f16x8(&xh)[MT], f16x8(&xl)[MT], f16x8(&wh)[NT],
+                        f16x8(&wl)[NT]) {
+    const int g = it / KS, ks = it % KS;
+    const _Float16* px = Xh + (row0 + l31 + (tap0 + g) * a.dil) * RS + ks * 16 + 8 * h;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const int ntile = ntile0 + nt;
-          if (ntile < nnt) {
-            const size_t widx = ((((size_t)ph * a.K + tap) * nks + gks) * nnt + ntile) * 64 + lane;
-            wh[nt] = WH[widx];
-            wl[nt] = WL[widx];
-          } else {
+    for (int mt = 0; mt < MT; ++mt) {
+      xh[mt] = *reinterpret_cast<const f16x8*>(px + mt * 32 * RS);
+      xl[mt] = *reinterpret_cast<const f16x8*>(px + mt * 32 * RS + XIMG);
+    }
+    const _Float16* pw = Wc + (((g * KS + ks) * NTB + wn * NT) * 64 + lane) * 8;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { wh[nt][j] = (_Float16)0.f; wl[nt][j] = (_Float16)0.f; }
-          }
-        }
+    for (int nt = 0; nt < NT; ++nt) {
+      wh[nt] = *reinterpret_cast<const f16x8*>(pw + nt * 512);
+      wl[nt] = *reinterpret_cast<const f16x8*>(pw + nt * 512 + WIMG);
+    }
+  };
+  auto mma = [&](const f16x8(&xh)[MT], const f16x8(&xl)[MT], const f16x8(&wh)[NT], const f16x8(&wl)[NT]) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const int off = (rbase + mt * 32) * RS + ks * 16 + 8 * h;
-          const f16x8 xh = *reinterpret_cast<const f16x8*>(Xh + off);
-          const f16x8 xl = *reinterpret_cast<const f16x8*>(Xl + off);
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            hh[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh[nt], hh[mt][nt], 0, 0, 0);
-            cr[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wl[nt], cr[mt][nt], 0, 0, 0);
-            cr[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wh[nt], cr[mt][nt], 0, 0, 0);
-          }
+      for (int nt = 0; nt < NT; ++nt) {
+        hh[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[mt], wh[nt], hh[mt][nt], 0, 0, 0);
+        cr[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[mt], wl[nt], cr[mt][nt], 0, 0, 0);
+        cr[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[mt], wh[nt], cr[mt][nt], 0, 0, 0);
+      }
+  };
+
+  x_issue(0);
+  w_issue(0);
+  x_write();
+  w_write(0);
+  __syncthreads();
+  f16x8 xhA[MT], xlA[MT], whA[NT], wlA[NT];
+  [[maybe_unused]] f16x8 xhB[MT], xlB[MT], whB[NT], wlB[NT];
+  for (int step = 0; step < nsteps; ++step) {
+    const int chunk = step / ns, sl = step - chunk * ns;
+    const bool more = step + 1 < nsteps;
+    const bool new_chunk = more && sl == ns - 1;
+    if (more) w_issue(step + 1);
+    if (new_chunk) x_issue(chunk + 1);
+    const _Float16* Wc = Wb + (step & 1) * 2 * WIMG;
+    const int tap0 = sl * G;
+    const int nit = ((a.K - tap0) < G ? (a.K - tap0) : G) * KS;
+    if constexpr (PF) {
+      // fragments one k-step ahead of the MFMAs (two named register sets)
+      load_frags(Wc, tap0, 0, xhA, xlA, whA, wlA);
+      for (int it = 0; it < nit; it += 2) {
+        if (it + 1 < nit) load_frags(Wc, tap0, it + 1, xhB, xlB, whB, wlB);
+        mma(xhA, xlA, whA, wlA);
+        if (it + 1 < nit) {
+          if (it + 2 < nit) load_frags(Wc, tap0, it + 2, xhA, xlA, whA, wlA);
+          mma(xhB, xlB, whB, wlB);
         }
       }
+    } else {
+      // register-tight tile: the SIMD's second wave covers the LDS latency
+      for (int it = 0; it < nit; ++it) {
+        load_frags(Wc, tap0, it, xhA, xlA, whA, wlA);
+        mma(xhA, xlA, whA, wlA);
+      }
+    }
+    if (more) {
+      if (new_chunk) {
+        __syncthreads();          // every wave is done reading the activation window
+        x_write();
+      }
+      w_write((step + 1) & 1);    // the other ring slot: last read one barrier ago
+      __syncthreads();
     }
   }
 
   // ---- epilogue: rows = time (registers), lane = output channel -> contiguous 128-byte rows
+  const int ntile0 = cb * NTB + wn * NT;
   float* outb = a.out + (size_t)b * a.o_bs;
   const float* resb = a.res ? a.res + (size_t)b * a.r_bs : nullptr;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const int ntile = ntile0 + nt;
-      if (ntile >= nnt) continue;
-      const int co = ntile * 32 + l31;
+      const int co = (ntile0 + nt) * 32 + l31;
       const float bias = a.bias ? a.bias[co] : 0.f;
       bool st[16];
       size_t oidx[16];
@@ -199,20 +273,23 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
   }
 }
 
-template <int MT, int NT, int WM, int WN, int CKC>
+template <int MT, int NT, int WM, int WN, int CKC, int G, bool PF>
 static hipError_t launch_cl_tile(const ClConvArgs& a, int B, hipStream_t s) {
   constexpr int BT = 32 * MT * WM;
-  constexpr size_t lds = (size_t)2 * (BT + CL_HALO) * (CKC + 8) * sizeof(_Float16);
+  constexpr size_t lds = ((size_t)2 * (BT + CL_HALO) * (CKC + 8) + (size_t)4 * G * (CKC / 16) * NT * WN * 512) *
+                         sizeof(_Float16);
+  static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
-  auto kern = cl_conv_f16s<MT, NT, WM, WN, CKC>;
+  auto kern = cl_conv_f16s<MT, NT, WM, WN, CKC, G, PF>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  const int nnt = a.Cout / 32, ncb = (nnt + NT * WN - 1) / (NT * WN);
-  dim3 grid((a.Nq + BT - 1) / BT, a.phases * ncb, B);
+  const int nnt = a.Cout / 32;
+  if (nnt % (NT * WN) || a.Cin % CKC) return hipErrorInvalidValue;
+  dim3 grid((a.Nq + BT - 1) / BT, a.phases * (nnt / (NT * WN)), B);
   hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, a);
   return hipGetLastError();
 }
@@ -223,13 +300,12 @@ hipError_t launch_cl_conv(const ClConvArgs& a, int B, hipStream_t s) {
     return hipErrorInvalidValue;
   if (a.Cin == 32) {
     if (a.Cout != 32) return hipErrorInvalidValue;
-    return launch_cl_tile<2, 1, 4, 1, 32>(a, B, s);
+    return launch_cl_tile<1, 1, 8, 1, 32, 8, true>(a, B, s);
   }
   if (a.Cin % 64) return hipErrorInvalidValue;
-  if (a.Cout == 32) return launch_cl_tile<1, 1, 4, 1, 64>(a, B, s);
-  if (a.Cout == 64) return launch_cl_tile<1, 2, 4, 1, 64>(a, B, s);
-  if (a.Cout % 128 == 0) return launch_cl_tile<2, 2, 2, 2, 64>(a, B, s);
-  return launch_cl_tile<1, 2, 4, 1, 64>(a, B, s);
+  if (a.Cout % 128 == 0) return launch_cl_tile<2, 2, 4, 2, 64, 1, false>(a, B, s);
+  if (a.Cout % 64 == 0) return launch_cl_tile<2, 1, 4, 2, 64, 2, true>(a, B, s);
+  return launch_cl_tile<1, 1, 8, 1, 64, 4, true>(a, B, s);
 }
 
 // ------------------------------------------------------------------------------------------
