@@ -42,7 +42,7 @@ def parse():
     p.add_argument("--workload", default="C3")
     p.add_argument("--batch", type=int, default=None, help="override utterances per GPU (debug)")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-sample", type=int, default=2, help="utterances of the batch timed on the CPU oracle")
+    p.add_argument("--cpu-sample", type=int, default=16, help="utterances of the batch timed on the CPU oracle")
     return p.parse_args()
 
 
@@ -109,18 +109,13 @@ def main():
     hps = vcfg.default_hparams()
     a, kw = vcfg.synthesizer_args(hps)
     net = SynthesizerTrn(*a, device=dev, **kw).eval()
+    from vispeech_amd.sharding import broadcast_weights, gather_batch, global_max
     sd = synth_state_dict(dims, seed=1234, infer_only=True) if rank == 0 or world == 1 else None
     if world == 1:
         net.load_state_dict(sd)
     else:
         # RCCL weight broadcast: rank 0 packs, everyone else adopts the broadcast arena
-        eng = net._engine
-        if rank == 0:
-            eng.set_weights(sd)
-            arena = eng.finalize()
-        else:
-            arena = eng.adopt()
-        dist.broadcast(arena, src=0)
+        broadcast_weights(net._engine, sd, src=0)
         torch.cuda.synchronize()
 
     wl = dict(WORKLOADS[args.workload])
@@ -134,20 +129,15 @@ def main():
     dur, f0, en = t(batch["duration"]), t(batch["f0"]), t(batch["energy"])
     tf_local = int(batch["frame_lengths"].max())
     valid_samples = 512 * int(batch["frame_lengths"].sum())
-    tf_t = torch.tensor([tf_local], dtype=torch.int64, device=dev)
-    if world > 1:
-        dist.all_reduce(tf_t, op=dist.ReduceOp.MAX)
-    tf_global = int(tf_t.item())
+    tf_global = global_max(tf_local, dev)
     noise = torch.zeros(B, dims.inter_channels, tf_global, dtype=torch.float32, device=dev)
     noise[:, :, :tf_local] = t(batch["noise"])
-    gathered = [torch.empty(B, 1, 512 * tf_global, dtype=torch.float32, device=dev) for _ in range(world)] \
-        if (world > 1 and rank == 0) else None
 
     def step():
         o, *_ = net.infer(ph, ln, sid=sid, noise_scale=0.667, duration_control=dur, pitch_control=f0,
                           energy_control=en, noise=noise, t_f=tf_global)
         if world > 1:
-            dist.gather(o, gathered, dst=0)
+            gather_batch(o, dst=0)          # final waveform gather on rank 0 (RCCL)
         return o
 
     for _ in range(args.warmup):
@@ -202,6 +192,15 @@ def main():
                          "alg_tflops": tfl, "alg_gbs": gbs, "hbm_frac": f_hbm, "mfma_issue_frac": f_mfma,
                          "note": "fp32 activations in HBM; f16 MFMA on split operands (3 MFMA per product), fp32-accurate"})
             dtype = "f32 (split-f16 MFMA, 3-term)"
+        traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(traffic_file):
+            try:
+                tr = json.load(open(traffic_file))
+                if tr.get("generator") == gen_mode and tr.get("utterances") == B:
+                    roof["traffic"] = tr["hbm_bytes_per_launch"]
+                    roof["traffic_source"] = tr.get("source")
+            except Exception:
+                pass
         roof.update({"launches": launches, "avg_launch_ms": conv_ms / max(launches, 1),
                      "alg_flops_per_launch": conv_flops / max(launches, 1),
                      "alg_bytes_per_launch": conv_bytes / max(launches, 1),

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""HBM bytes per launch of the dominant kernel from two rocprofv3 --pmc passes (FETCH_SIZE and
+WRITE_SIZE collected separately, as MI355X_MICROARCH.md prescribes: FETCH_SIZE takes 3 of the 4 TCC
+slots, WRITE_SIZE 2).  Units are KiB; on gfx950 FETCH_SIZE reports exactly half of the bytes of a
+wide (16 B/lane) coalesced streaming read, so the read side is doubled; WRITE_SIZE is taken as is.
+usage: traffic_from_pmc.py <kernel substr> <fetch counter_collection.csv> <write counter_collection.csv> <generator> <utterances>"""
+import csv, json, sys
+sub, fcsv, wcsv, gen, utt = sys.argv[1:6]
+def total(path, counter):
+    s = 0.0; n = 0
+    for r in csv.DictReader(open(path)):
+        if sub in r['Kernel_Name'] and r['Counter_Name'] == counter:
+            s += float(r['Counter_Value']); n += 1
+    return s, n
+f, nf = total(fcsv, 'FETCH_SIZE')
+w, nw = total(wcsv, 'WRITE_SIZE')
+assert nf == nw and nf > 0, (nf, nw)
+fetch_b, write_b = 2.0 * f * 1024.0, w * 1024.0
+out = {"kernel": sub, "generator": gen, "utterances": int(utt), "launches": nf,
+       "fetch_bytes_per_launch": fetch_b / nf, "write_bytes_per_launch": write_b / nf,
+       "hbm_bytes_per_launch": (fetch_b + write_b) / nf,
+       "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), KiB units, FETCH_SIZE x2 (gfx950 "
+                 "wide-read correction, MI355X_MICROARCH.md section HBM)"}
+print(json.dumps(out, indent=1))
