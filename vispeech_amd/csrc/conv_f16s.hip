@@ -61,19 +61,31 @@ void pack_cl_weights(uint16_t* hi, uint16_t* lo, int Cout, int Cin, int K, int p
 // slice ahead, so the fetch latency hides under the MFMAs of the current slice).  Every wave then
 // reads both operands' fragments from LDS (ds_read_b128, conflict-free) one k-step ahead of the
 // MFMAs that consume them.
+//
+// Addressing: rocprofv3 --pmc showed the first versions issuing 18-57 VALU instructions per MFMA,
+// nearly all 64-bit index arithmetic and per-element bounds branches (the epilogue alone was ~1100
+// VALU + 650 SALU per tile).  Every activation access therefore goes through a per-utterance BUFFER
+// descriptor: the hardware range check returns 0 for rows before/after the utterance (= the conv's
+// zero padding) and drops stores outside it (tile edges, polyphase rows), so there is no bounds
+// code at all; a lane's offset is (per-tile lane constant) + (wave-uniform row term) = one v_add.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 template <int MT, int NT, int WM, int WN, int CKC, int G, bool PF>
 __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
   constexpr int BT = 32 * MT * WM;
   constexpr int RS = CKC + 8;                 // LDS row stride of the activation images (halfs)
   constexpr int NTH = 64 * WM * WN;
-  constexpr int WMAX = BT + CL_HALO;
   constexpr int C4 = CKC / 4;                 // float4 per staged activation row
-  constexpr int NL = (WMAX * C4 + NTH - 1) / NTH;
+  constexpr int ROWS_PER_U = NTH / C4;        // rows covered by one staging sweep of the block
+  constexpr int NL = (BT + CL_HALO + ROWS_PER_U - 1) / ROWS_PER_U;
+  constexpr int WMAX = NL * ROWS_PER_U;       // staged rows (>= BT + halo, whole sweeps)
   constexpr int KS = CKC / 16;                // k-steps per tap and chunk
   constexpr int NTB = NT * WN;                // 32-channel output tiles per block
   constexpr int XIMG = WMAX * RS;             // halfs per activation image
   constexpr int WIMG = G * KS * NTB * 64 * 8; // halfs per weight-slice image
-  constexpr int NWL = (2 * WIMG / 8 + NTH - 1) / NTH;   // 16-byte units per thread per slice (hi+lo)
+  constexpr int NWV = NTH / 64;
+  constexpr int NBLK = 2 * G * KS * NTB;      // 1-KiB fragment blocks per slice (hi + lo)
+  constexpr int NWL = (NBLK + NWV - 1) / NWV; // blocks per wave per slice
   extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
   _Float16* const Xh = lds;                   // [WMAX][RS] hi, then lo
   _Float16* const Wb = lds + 2 * XIMG;        // 2 x (hi image, lo image)
@@ -88,95 +100,104 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
   const int ncb = nnt / NTB;
   const int ph = blockIdx.y / ncb, cb = blockIdx.y - ph * ncb;
   const int row0 = wm * MT * 32;
-  const int W = BT + (a.K - 1) * a.dil;
   const int nchunks = a.Cin / CKC;
-  const int total4 = W * C4;
   const int ns = (a.K + G - 1) / G;           // weight slices per chunk
   const int nsteps = nchunks * ns;
 
+  // per-utterance buffer descriptors (wave-uniform)
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x) + (size_t)b * a.x_bs, 0, a.T_in * a.x_ts * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+      a.out + (size_t)b * a.o_bs, 0, a.T_store * a.o_ts * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr_ = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.res ? a.res : a.out) + (size_t)b * (a.res ? a.r_bs : a.o_bs), 0,
+      a.T_store * (a.res ? a.r_ts : a.o_ts) * 4, 0x00020000);
+
+  // accumulators start at the bias (lane = output channel in the D layout)
   f32x16 hh[MT][NT], cr[MT][NT];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+  for (int nt = 0; nt < NT; ++nt) {
+    const float bias = a.bias ? a.bias[(cb * NTB + wn * NT + nt) * 32 + l31] : 0.f;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { hh[mt][nt][r] = 0.f; cr[mt][nt][r] = 0.f; }
+      for (int r = 0; r < 16; ++r) { hh[mt][nt][r] = bias; cr[mt][nt][r] = 0.f; }
+  }
 
-  const float* xb = a.x + (size_t)b * a.x_bs;
   const uint4* WHg = reinterpret_cast<const uint4*>(a.wh);
   const uint4* WLg = reinterpret_cast<const uint4*>(a.wl);
 
-  // ---- activation staging (issue early / convert + write late)
-  float4 sv[NL];
+  // ---- activation staging (issue early / convert + write late); per-lane parts computed once
+  const int st_row = tid / C4, st_c4 = tid % C4;
+  const int st_voff = (st_row * a.x_ts + 4 * st_c4) * 4;                   // bytes
+  const int st_loff = st_row * RS + 4 * st_c4;                             // halfs
+  u32x4 sv[NL];
+  const float slope = a.in_act ? a.in_slope : 1.f;
   auto x_issue = [&](int chunk) {
+    const int base = ((t0 - a.pad) * a.x_ts + chunk * CKC) * 4;            // uniform, may be negative
 #pragma unroll
-    for (int u = 0; u < NL; ++u) {
-      const int idx = u * NTH + tid;
-      const int row = idx / C4, c4 = idx % C4;
-      const int t = t0 - a.pad + row;
-      sv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (idx < total4 && t >= 0 && t < a.T_in)
-        sv[u] = *reinterpret_cast<const float4*>(xb + (size_t)t * a.x_ts + chunk * CKC + 4 * c4);
-    }
+    for (int u = 0; u < NL; ++u)
+      sv[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, st_voff + (base + u * ROWS_PER_U * a.x_ts * 4), 0, 0);
   };
   auto x_write = [&]() {
 #pragma unroll
     for (int u = 0; u < NL; ++u) {
-      const int idx = u * NTH + tid;
-      if (idx >= total4) continue;
-      const int row = idx / C4, c4 = idx % C4;
-      float e[4] = {sv[u].x, sv[u].y, sv[u].z, sv[u].w};
+      const float e[4] = {__uint_as_float(sv[u].x), __uint_as_float(sv[u].y), __uint_as_float(sv[u].z),
+                          __uint_as_float(sv[u].w)};
       f16x4 eh, el;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        float x = e[k];
-        if (a.in_act) x = x > 0.f ? x : x * a.in_slope;
+        // leaky-relu as max(x, slope*x), 0 <= slope <= 1 (slope 1 = identity); one v_mul + one
+        // v_max (fmaxf() would add NaN-canonicalising instructions)
+        float x;
+        asm("v_max_f32 %0, %1, %2" : "=v"(x) : "v"(e[k]), "v"(e[k] * slope));
         const _Float16 xh = (_Float16)x;
         eh[k] = xh;
         el[k] = (_Float16)((x - (float)xh) * 2048.f);
       }
-      *reinterpret_cast<f16x4*>(Xh + row * RS + 4 * c4) = eh;
-      *reinterpret_cast<f16x4*>(Xh + XIMG + row * RS + 4 * c4) = el;
+      _Float16* dst = Xh + st_loff + u * (ROWS_PER_U * RS);  // compile-time stride
+      *reinterpret_cast<f16x4*>(dst) = eh;
+      *reinterpret_cast<f16x4*>(dst + XIMG) = el;
     }
   };
   // ---- weight-slice staging: slice (chunk, sl) = taps [sl*G, sl*G+G) x k-steps of the chunk x the
-  //      block's NTB output tiles; 16-byte units, unit index = ((g*KS + ks)*NTB + ntl)*64 + lane
+  //      block's NTB output tiles; a wave copies whole 1-KiB fragment blocks, block index
+  //      ((img*G + g)*KS + ks)*NTB + ntl is wave-uniform
   uint4 wv[NWL];
   auto w_issue = [&](int step) {
     const int chunk = step / ns, sl = step - chunk * ns;
 #pragma unroll
     for (int u = 0; u < NWL; ++u) {
-      const int idx = u * NTH + tid;
-      const int img = idx / (WIMG / 8), un = idx % (WIMG / 8);
-      const int ln = un % 64, ntl = (un / 64) % NTB, ks = (un / (64 * NTB)) % KS, g = un / (64 * NTB * KS);
+      const int blk = u * NWV + wave;
+      const int ntl = blk % NTB, ks = (blk / NTB) % KS, g = (blk / (NTB * KS)) % G, img = blk / (NTB * KS * G);
       const int tap = sl * G + g;
       wv[u] = make_uint4(0u, 0u, 0u, 0u);
-      if (img < 2 && tap < a.K) {
-        const size_t src = ((((size_t)ph * a.K + tap) * nks + chunk * KS + ks) * nnt + cb * NTB + ntl) * 64 + ln;
-        wv[u] = img == 0 ? WHg[src] : WLg[src];
+      if (blk < NBLK && tap < a.K) {
+        const size_t src = ((((size_t)ph * a.K + tap) * nks + chunk * KS + ks) * nnt + cb * NTB + ntl) * 64;
+        wv[u] = (img == 0 ? WHg : WLg)[src + lane];
       }
     }
   };
   auto w_write = [&](int buf) {
-    uint4* dst = reinterpret_cast<uint4*>(Wb + buf * 2 * WIMG);
+    uint4* dst = reinterpret_cast<uint4*>(Wb + buf * 2 * WIMG) + tid;
 #pragma unroll
-    for (int u = 0; u < NWL; ++u) {
-      const int idx = u * NTH + tid;
-      if (idx < 2 * WIMG / 8) dst[idx] = wv[u];
-    }
+    for (int u = 0; u < NWL; ++u)
+      if (u * NWV + wave < NBLK) dst[u * NTH] = wv[u];
   };
 
-  // ---- fragment loads (LDS) and the 3-term product
+  // ---- fragment loads (LDS): per-lane bases once, wave-uniform (tap, k-step) offsets per call
+  const int xf_lane = (row0 + l31) * RS + 8 * h;               // halfs
+  const int wf_lane = (wn * NT * 64 + lane) * 8;               // halfs
   auto load_frags = [&](const _Float16* Wc, int tap0, int it, f16x8(&xh)[MT], f16x8(&xl)[MT], f16x8(&wh)[NT],
                         f16x8(&wl)[NT]) {
     const int g = it / KS, ks = it % KS;
-    const _Float16* px = Xh + (row0 + l31 + (tap0 + g) * a.dil) * RS + ks * 16 + 8 * h;
+    const _Float16* px = Xh + xf_lane + ((tap0 + g) * a.dil * RS + ks * 16);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       xh[mt] = *reinterpret_cast<const f16x8*>(px + mt * 32 * RS);
       xl[mt] = *reinterpret_cast<const f16x8*>(px + mt * 32 * RS + XIMG);
     }
-    const _Float16* pw = Wc + (((g * KS + ks) * NTB + wn * NT) * 64 + lane) * 8;
+    const _Float16* pw = Wc + wf_lane + (g * KS + ks) * NTB * 512;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       wh[nt] = *reinterpret_cast<const f16x8*>(pw + nt * 512);
@@ -238,37 +259,45 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
     }
   }
 
-  // ---- epilogue: rows = time (registers), lane = output channel -> contiguous 128-byte rows
-  const int ntile0 = cb * NTB + wn * NT;
-  float* outb = a.out + (size_t)b * a.o_bs;
-  const float* resb = a.res ? a.res + (size_t)b * a.r_bs : nullptr;
+  // ---- epilogue.  D tile: register r is time row rr(r) = (r&3) + 8*(r>>2) (+4h), lane = channel.
+  //      Offsets (bytes, 32-bit) = lane part once per (mt, nt) + wave-uniform row part; rows outside
+  //      [0, T_store) fall outside the descriptor: loads give 0, stores are dropped.
+  const int n_wave = a.phases > 1 ? a.phases * (t0 + row0) + ph - a.ups_p : (t0 + row0);  // uniform, may be < 0
+  const int ostep = a.phases * a.o_ts * 4, rstep = a.phases * (a.res ? a.r_ts : a.o_ts) * 4;  // bytes per D row
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const int co = (ntile0 + nt) * 32 + l31;
-      const float bias = a.bias ? a.bias[co] : 0.f;
-      bool st[16];
-      size_t oidx[16];
-      float rv[16], pv[16];
+      const int co = (cb * NTB + wn * NT + nt) * 32 + l31;
+      const int lo = (4 * h + mt * 32) * ostep + co * 4 + n_wave * a.o_ts * 4;
+      const int lr = (4 * h + mt * 32) * rstep + co * 4 + n_wave * (a.res ? a.r_ts : a.o_ts) * 4;
+      // uniform conditions hoisted: each optional operand is one block of 16 loads + 16 adds
+      float v[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int q = t0 + row0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int n = a.phases > 1 ? a.phases * q + ph - a.ups_p : q;
-        st[r] = q < a.Nq && n >= 0 && n < a.T_store;
-        oidx[r] = (size_t)n * a.o_ts + co;
-        rv[r] = (resb && st[r]) ? resb[(size_t)n * a.r_ts + co] : 0.f;
-        pv[r] = (a.acc_prev && st[r]) ? outb[oidx[r]] : 0.f;
+      for (int r = 0; r < 16; ++r) v[r] = hh[mt][nt][r] + cr[mt][nt][r] * (1.f / 2048.f);
+      if (a.res) {
+        float rv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          rv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr_, lr + ((r & 3) + 8 * (r >> 2)) * rstep, 0, 0));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += rv[r];
+      }
+      if (a.acc_prev) {
+        float pv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          pv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ro, lo + ((r & 3) + 8 * (r >> 2)) * ostep, 0, 0));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += pv[r];
+      }
+      if (a.div != 1.f) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] /= a.div;
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (!st[r]) continue;
-        float v = hh[mt][nt][r] + cr[mt][nt][r] * (1.f / 2048.f) + bias;
-        if (resb) v += rv[r];
-        if (a.acc_prev) v += pv[r];
-        if (a.div != 1.f) v /= a.div;
-        outb[oidx[r]] = v;
-      }
+      for (int r = 0; r < 16; ++r)
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), ro, lo + ((r & 3) + 8 * (r >> 2)) * ostep, 0, 0);
     }
   }
 }
@@ -276,7 +305,9 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
 template <int MT, int NT, int WM, int WN, int CKC, int G, bool PF>
 static hipError_t launch_cl_tile(const ClConvArgs& a, int B, hipStream_t s) {
   constexpr int BT = 32 * MT * WM;
-  constexpr size_t lds = ((size_t)2 * (BT + CL_HALO) * (CKC + 8) + (size_t)4 * G * (CKC / 16) * NT * WN * 512) *
+  constexpr int RPU = (64 * WM * WN) / (CKC / 4);
+  constexpr int WMAXL = (BT + CL_HALO + RPU - 1) / RPU * RPU;
+  constexpr size_t lds = ((size_t)2 * WMAXL * (CKC + 8) + (size_t)4 * G * (CKC / 16) * NT * WN * 512) *
                          sizeof(_Float16);
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
