@@ -329,14 +329,14 @@ hipError_t launch_cl_conv(const ClConvArgs& a, int B, hipStream_t s) {
   if ((a.K - 1) * a.dil > CL_HALO || a.K < 1 || a.Nq <= 0 || B <= 0 || a.Cout % 32 || a.Cin % 32 || a.phases < 1 ||
       (a.x_ts & 3) || (a.x_bs & 3) || (reinterpret_cast<uintptr_t>(a.x) & 15))
     return hipErrorInvalidValue;
-  if (a.Cin == 32) {
-    if (a.Cout != 32) return hipErrorInvalidValue;
-    return launch_cl_tile<1, 1, 8, 1, 32, 8, true>(a, B, s);
-  }
-  if (a.Cin % 64) return hipErrorInvalidValue;
-  if (a.Cout % 128 == 0) return launch_cl_tile<2, 2, 4, 2, 64, 1, false>(a, B, s);
-  if (a.Cout % 64 == 0) return launch_cl_tile<2, 1, 4, 2, 64, 2, true>(a, B, s);
-  return launch_cl_tile<1, 1, 8, 1, 64, 4, true>(a, B, s);
+  // <MT, NT, WM, WN, CKC, G, PF>; tile choices measured on MI355X (profiles/r01_tile_experiments.txt):
+  //  * >= 128 output channels: 8 waves x (64 rows x 64 channels), 64-channel chunks, one block per CU
+  //    (2 blocks of 4 waves, or fragment prefetch at 256 VGPRs, were both slower);
+  //  * 64 / 32 output channels: LDS kept under 80 KiB (32-channel chunks, small weight ring) so that
+  //    TWO blocks share a CU and overlap each other's load / MFMA / store phases.
+  if (a.Cout % 128 == 0 && a.Cin % 64 == 0) return launch_cl_tile<2, 2, 4, 2, 64, 1, false>(a, B, s);
+  if (a.Cout % 64 == 0) return launch_cl_tile<2, 1, 4, 2, 32, 1, true>(a, B, s);
+  return launch_cl_tile<1, 1, 8, 1, 32, 2, true>(a, B, s);
 }
 
 // ------------------------------------------------------------------------------------------
