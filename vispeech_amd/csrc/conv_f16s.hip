@@ -140,20 +140,24 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
       sv[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, st_voff + (base + u * ROWS_PER_U * a.x_ts * 4), 0, 0);
   };
   auto x_write = [&]() {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int u = 0; u < NL; ++u) {
-      const float e[4] = {__uint_as_float(sv[u].x), __uint_as_float(sv[u].y), __uint_as_float(sv[u].z),
-                          __uint_as_float(sv[u].w)};
+      // two elements at a time so that the multiplies / subtract / converts can use the packed forms
+      // (v_pk_mul_f32, v_pk_add_f32, v_cvt_pk_f16_f32); leaky-relu = max(x, slope*x), 0 <= slope <= 1
       f16x4 eh, el;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        // leaky-relu as max(x, slope*x), 0 <= slope <= 1 (slope 1 = identity); one v_mul + one
-        // v_max (fmaxf() would add NaN-canonicalising instructions)
-        float x;
-        asm("v_max_f32 %0, %1, %2" : "=v"(x) : "v"(e[k]), "v"(e[k] * slope));
-        const _Float16 xh = (_Float16)x;
-        eh[k] = xh;
-        el[k] = (_Float16)((x - (float)xh) * 2048.f);
+      for (int k = 0; k < 2; ++k) {
+        f32x2 x = {__uint_as_float(k == 0 ? sv[u].x : sv[u].z), __uint_as_float(k == 0 ? sv[u].y : sv[u].w)};
+        const f32x2 y = x * slope;
+        asm("v_max_f32 %0, %1, %2" : "=v"(x.x) : "v"(x.x), "v"(y.x));
+        asm("v_max_f32 %0, %1, %2" : "=v"(x.y) : "v"(x.y), "v"(y.y));
+        const f16x2 xh = __builtin_convertvector(x, f16x2);
+        const f32x2 back = __builtin_convertvector(xh, f32x2);
+        const f16x2 xl = __builtin_convertvector((x - back) * 2048.f, f16x2);
+        eh[2 * k] = xh.x; eh[2 * k + 1] = xh.y;
+        el[2 * k] = xl.x; el[2 * k + 1] = xl.y;
       }
       _Float16* dst = Xh + st_loff + u * (ROWS_PER_U * RS);  // compile-time stride
       *reinterpret_cast<f16x4*>(dst) = eh;
