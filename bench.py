@@ -34,6 +34,10 @@ ALG_BYTES_PER_SAMPLE = 13045     # SURVEY.md 8(d), fp32 end-to-end layer-boundar
 ALG_FLOPS_PER_SAMPLE = 1.641e6
 
 
+WL_TEXT = {"C1": "zh utterance (~5 s)", "C2": "zh utterances (~5 s each)", "C3": "mixed zh/ja utterances (~5 s each)",
+           "C4": "mixed zh/ja utterances (~5 s each)", "C5": "long-form utterance (60 s, 5168 frames)"}
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -210,7 +214,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "rtf": (dt / args.steps) / audio_s,
-            "config": {"workload": f"{args.workload}: {B} mixed zh/ja utterances per GPU (~5 s each, 44.1 kHz, hop 512), "
+            "config": {"workload": f"{args.workload}: {B} {WL_TEXT.get(args.workload, 'utterances')} per GPU, 44.1 kHz, hop 512, "
                                    "phoneme/duration/F0/energy/noise supplied, random-init (synthetic) weights of "
                                    "configs/config.json",
                        "utterances_per_gpu": B, "padded_frames": tf_global,
