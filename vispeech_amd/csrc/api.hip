@@ -366,7 +366,7 @@ void run_generator_cl(Run& r, int B, int T, T3 z, const int64_t* in_lengths, con
     Tn = Tout;
   }
   if (!r.dry() && r.ok())
-    r.chk(launch_conv_post_cl(buf[cur], Tn * ch, ch, r.A(m.post_w), m.post_c, m.post_k, 0.01f, o, Tn, B, (int)Tn, r.s),
+    r.chk(launch_conv_post_cl(buf[cur], Tn * ch, ch, r.A(m.post_wt), m.post_c, m.post_k, 0.01f, o, Tn, B, (int)Tn, r.s),
           "conv_post_cl");
 }
 

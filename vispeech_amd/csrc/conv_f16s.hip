@@ -371,48 +371,57 @@ hipError_t launch_transpose_ct(const float* x, long x_bs, long x_cs, float* y, l
 
 // ------------------------------------------------------------------------------------------
 // conv_post on a channels-last input: o[b][t] = tanh(sum_j sum_c w[c][j] * lrelu(x[b][t+j-pad][c]))
-// (reference models.py:286-288).  Block = 256 outputs; the (256+K-1) x C window is one contiguous
-// chunk of HBM; LDS rows padded to C+1 floats (conflict-free column walks).
+// (reference models.py:286-288; slope 0.01 = F.leaky_relu's default, gotcha G1).  Block = 256 outputs.
+// The (256+K-1) x C window is one contiguous span of HBM: staged with 16-byte buffer loads (rows
+// outside the utterance read as 0 = the zero padding), activated once, kept in LDS with rows padded
+// to C+4 floats (16-byte aligned, conflict-free ds_read_b128 down a column of rows); the weights are
+// read through the scalar unit (uniform addresses).
 constexpr int CPL_TILE = 256;
-__global__ void __launch_bounds__(256) conv_post_cl_kernel(const float* __restrict__ x, long x_bs, int x_ts,
-                                                           const float* __restrict__ w, int C, int K, float slope,
-                                                           float* __restrict__ o, long o_bs, int T) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int RSf = C + 1;
-  float* xs = sm;                             // [CPL_TILE + K - 1][C + 1]
-  float* ws = sm + (CPL_TILE + 8) * RSf;      // [K][C]  (tap-major for the inner loop)
+template <int C>
+__global__ void __launch_bounds__(256) conv_post_cl_kernel(const float* __restrict__ x, long x_bs,
+                                                           const float* __restrict__ wt /* [K][C] */, int K,
+                                                           float slope, float* __restrict__ o, long o_bs, int T) {
+  constexpr int RSF = C + 4;
+  constexpr int C4 = C / 4;
+  __shared__ __attribute__((aligned(16))) float xs[(CPL_TILE + 8) * RSF];
   const int b = blockIdx.y, t0 = blockIdx.x * CPL_TILE, pad = (K - 1) / 2;
   const int rows = CPL_TILE + K - 1;
-  const float* xb = x + (size_t)b * x_bs;
-  for (int idx = threadIdx.x; idx < C * K; idx += 256) {
-    const int j = idx / C, c = idx % C;
-    ws[idx] = w[c * K + j];
-  }
-  for (int idx = threadIdx.x; idx < rows * C; idx += 256) {
-    const int row = idx / C, c = idx % C;
-    const int t = t0 - pad + row;
-    float v = 0.f;
-    if (t >= 0 && t < T) {
-      v = xb[(size_t)t * x_ts + c];
-      v = v > 0.f ? v : v * slope;
-    }
-    xs[row * RSf + c] = v;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x) + (size_t)b * x_bs, 0,
+                                                                      T * C * 4, 0x00020000);
+  const int base = (t0 - pad) * C * 4;
+  for (int idx = threadIdx.x; idx < rows * C4; idx += 256) {
+    const int row = idx / C4, c4 = idx % C4;
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, base + idx * 16, 0, 0);
+    float e[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e[k] = e[k] > 0.f ? e[k] : e[k] * slope;
+    *reinterpret_cast<float4*>(xs + row * RSF + 4 * c4) = make_float4(e[0], e[1], e[2], e[3]);
   }
   __syncthreads();
   const int t = t0 + threadIdx.x;
   float acc = 0.f;
-  for (int c = 0; c < C; ++c) {
-#pragma unroll 7
-    for (int j = 0; j < K; ++j) acc += ws[j * C + c] * xs[(threadIdx.x + j) * RSf + c];
+  for (int j = 0; j < K; ++j) {
+    const float* xr = xs + (threadIdx.x + j) * RSF;
+    const float* wr = wt + j * C;             // uniform -> scalar loads
+#pragma unroll
+    for (int c4 = 0; c4 < C4; ++c4) {
+      const float4 xv = *reinterpret_cast<const float4*>(xr + 4 * c4);
+      acc += wr[4 * c4 + 0] * xv.x;
+      acc += wr[4 * c4 + 1] * xv.y;
+      acc += wr[4 * c4 + 2] * xv.z;
+      acc += wr[4 * c4 + 3] * xv.w;
+    }
   }
   if (t < T) o[(size_t)b * o_bs + t] = tanhf(acc);
 }
 hipError_t launch_conv_post_cl(const float* x, long x_bs, int x_ts, const float* w, int C, int K, float slope,
                                float* o, long o_bs, int B, int T, hipStream_t s) {
-  if (K > 8 || C > 64) return hipErrorInvalidValue;
-  const size_t lds = ((size_t)(CPL_TILE + 8) * (C + 1) + (size_t)K * C) * sizeof(float);
-  hipLaunchKernelGGL(conv_post_cl_kernel, dim3((T + CPL_TILE - 1) / CPL_TILE, B), dim3(256), lds, s, x, x_bs, x_ts,
-                     w, C, K, slope, o, o_bs, T);
+  if (K > 8 || x_ts != C || (C != 32 && C != 64)) return hipErrorInvalidValue;
+  dim3 grid((T + CPL_TILE - 1) / CPL_TILE, B);
+  if (C == 32)
+    hipLaunchKernelGGL(conv_post_cl_kernel<32>, grid, dim3(256), 0, s, x, x_bs, w, K, slope, o, o_bs, T);
+  else
+    hipLaunchKernelGGL(conv_post_cl_kernel<64>, grid, dim3(256), 0, s, x, x_bs, w, K, slope, o, o_bs, T);
   return hipGetLastError();
 }
 

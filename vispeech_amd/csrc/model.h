@@ -70,7 +70,8 @@ struct Model {
   std::vector<Conv> ups;
   std::vector<ClConv> ups_h;
   std::vector<ResBlockW> rbs;
-  size_t post_w = 0;
+  size_t post_w = 0;    // conv_post weight [C][K] (reference layout)
+  size_t post_wt = 0;   // the same, tap-major [K][C] for the channels-last kernel
   int post_k = 7, post_c = 32;
   size_t total_floats = 0;
   bool has_cl = false;  // split-f16 channels-last generator weights present

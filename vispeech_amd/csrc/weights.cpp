@@ -300,6 +300,7 @@ int plan_model(vsp_ctx* ctx) {
   m.post_c = ch;
   m.post_k = 7;
   m.post_w = p.raw((size_t)ch * 7);
+  m.post_wt = p.raw((size_t)ch * 7);
   m.total_floats = p.cur;
   return VSP_OK;
 }
@@ -557,6 +558,9 @@ int fill_model(vsp_ctx* ctx, std::vector<float>& arena) {
     }
   }
   f.copy_raw(m.post_w, "dec.conv_post.weight", (size_t)m.post_c * m.post_k);
+  if (f.ok)
+    for (int c2 = 0; c2 < m.post_c; ++c2)
+      for (int j = 0; j < m.post_k; ++j) arena[m.post_wt + (size_t)j * m.post_c + c2] = arena[m.post_w + (size_t)c2 * m.post_k + j];
   if (!f.ok) return ctx->fail(VSP_ERR_STATE, "missing weight: %s", f.missing.c_str());
   return VSP_OK;
 }
