@@ -209,14 +209,23 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
     }
   };
   auto mma = [&](const f16x8(&xh)[MT], const f16x8(&xl)[MT], const f16x8(&wh)[NT], const f16x8(&wl)[NT]) {
+    // the three products are issued tile-interleaved so that the two MFMAs that chain on the same
+    // CROSS accumulator are never back to back
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
+      for (int nt = 0; nt < NT; ++nt)
         hh[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[mt], wh[nt], hh[mt][nt], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
         cr[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[mt], wl[nt], cr[mt][nt], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
         cr[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[mt], wh[nt], cr[mt][nt], 0, 0, 0);
-      }
   };
 
   x_issue(0);
