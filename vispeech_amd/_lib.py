@@ -11,7 +11,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvispeech_hip.so")
+LIB_PATH = os.environ.get("VSP_LIB_PATH") or os.path.join(_HERE, "lib", "libvispeech_hip.so")
 
 VSP_MAX_LIST = 8
 

@@ -70,7 +70,13 @@ void pack_cl_weights(uint16_t* hi, uint16_t* lo, int Cout, int Cin, int K, int p
 // code at all; a lane's offset is (per-tile lane constant) + (wave-uniform row term) = one v_add.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int MT, int NT, int WM, int WN, int CKC, int G, bool PF>
+// VSP_DIAG: timing-only ablation builds (tools/ablate.sh); bit 0 no MFMA, bit 1 no weight-slice loads,
+// bit 2 no activation loads, bit 3 no epilogue memory traffic.  0 in the product build.
+#ifndef VSP_DIAG
+#define VSP_DIAG 0
+#endif
+
+template <int MT, int NT, int WM, int WN, int CKC, int G, bool PF, int WD>
 __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
   constexpr int BT = 32 * MT * WM;
   constexpr int RS = CKC + 8;                 // LDS row stride of the activation images (halfs)
@@ -137,7 +143,8 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
     const int base = ((t0 - a.pad) * a.x_ts + chunk * CKC) * 4;            // uniform, may be negative
 #pragma unroll
     for (int u = 0; u < NL; ++u)
-      sv[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, st_voff + (base + u * ROWS_PER_U * a.x_ts * 4), 0, 0);
+      sv[u] = (VSP_DIAG & 4) ? u32x4{1u, 2u, 3u, 4u}
+                             : __builtin_amdgcn_raw_buffer_load_b128(rx, st_voff + (base + u * ROWS_PER_U * a.x_ts * 4), 0, 0);
   };
   auto x_write = [&]() {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -167,8 +174,13 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
   // ---- weight-slice staging: slice (chunk, sl) = taps [sl*G, sl*G+G) x k-steps of the chunk x the
   //      block's NTB output tiles; a wave copies whole 1-KiB fragment blocks, block index
   //      ((img*G + g)*KS + ks)*NTB + ntl is wave-uniform
-  uint4 wv[NWL];
-  auto w_issue = [&](int step) {
+  // Slices are requested WD steps ahead of their use into WD rotating register sets (one slice is
+  // 32 KiB from L2: with a single slice in flight the weight stream is latency-bound -- measured:
+  // the kernel WITHOUT its MFMAs still took 70 % of the time); the LDS ring stays at two slots,
+  // slice s+1 is written at the end of step s.
+  static_assert(WD >= 1 && WD <= 3, "prefetch distance");
+  uint4 wq[WD][NWL];
+  auto w_issue = [&](int step, uint4(&wv)[NWL]) {
     const int chunk = step / ns, sl = step - chunk * ns;
 #pragma unroll
     for (int u = 0; u < NWL; ++u) {
@@ -176,13 +188,13 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
       const int ntl = blk % NTB, ks = (blk / NTB) % KS, g = (blk / (NTB * KS)) % G, img = blk / (NTB * KS * G);
       const int tap = sl * G + g;
       wv[u] = make_uint4(0u, 0u, 0u, 0u);
-      if (blk < NBLK && tap < a.K) {
+      if (blk < NBLK && tap < a.K && (VSP_DIAG & 2) == 0) {
         const size_t src = ((((size_t)ph * a.K + tap) * nks + chunk * KS + ks) * nnt + cb * NTB + ntl) * 64;
         wv[u] = (img == 0 ? WHg : WLg)[src + lane];
       }
     }
   };
-  auto w_write = [&](int buf) {
+  auto w_write = [&](int buf, const uint4(&wv)[NWL]) {
     uint4* dst = reinterpret_cast<uint4*>(Wb + buf * 2 * WIMG) + tid;
 #pragma unroll
     for (int u = 0; u < NWL; ++u)
@@ -209,6 +221,13 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
     }
   };
   auto mma = [&](const f16x8(&xh)[MT], const f16x8(&xl)[MT], const f16x8(&wh)[NT], const f16x8(&wl)[NT]) {
+    if constexpr ((VSP_DIAG & 1) != 0) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) asm volatile("" ::"v"(xh[mt]), "v"(xl[mt]));
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) asm volatile("" ::"v"(wh[nt]), "v"(wl[nt]));
+      return;
+    }
     // the three products are issued tile-interleaved so that the two MFMAs that chain on the same
     // CROSS accumulator are never back to back
 #pragma unroll
@@ -229,17 +248,21 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
   };
 
   x_issue(0);
-  w_issue(0);
+  w_issue(0, wq[0]);
   x_write();
-  w_write(0);
+  w_write(0, wq[0]);
+#pragma unroll
+  for (int d = 1; d < WD; ++d)
+    if (d < nsteps) w_issue(d, wq[d % WD]);
   __syncthreads();
   f16x8 xhA[MT], xlA[MT], whA[NT], wlA[NT];
   [[maybe_unused]] f16x8 xhB[MT], xlB[MT], whB[NT], wlB[NT];
-  for (int step = 0; step < nsteps; ++step) {
+  // one step; `ld` receives slice step+WD, `st` holds slice step+1
+  auto step_body = [&](int step, uint4(&ld)[NWL], const uint4(&st)[NWL]) {
     const int chunk = step / ns, sl = step - chunk * ns;
     const bool more = step + 1 < nsteps;
     const bool new_chunk = more && sl == ns - 1;
-    if (more) w_issue(step + 1);
+    if (step + WD < nsteps) w_issue(step + WD, ld);
     if (new_chunk) x_issue(chunk + 1);
     const _Float16* Wc = Wb + (step & 1) * 2 * WIMG;
     const int tap0 = sl * G;
@@ -267,8 +290,59 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
         __syncthreads();          // every wave is done reading the activation window
         x_write();
       }
-      w_write((step + 1) & 1);    // the other ring slot: last read one barrier ago
+      w_write((step + 1) & 1, st);  // the other ring slot: last read one barrier ago
       __syncthreads();
+    }
+  };
+  // slice j lives in register set j % WD: step s loads into set s % WD (freed at the end of step
+  // s-1) and stores from set (s+1) % WD
+  if constexpr (WD == 1) {
+    // plain loop (kept literally separate from step_body: the register allocation of this form
+    // fits the 128-VGPR budget of the two-blocks-per-CU tiles)
+    for (int step = 0; step < nsteps; ++step) {
+      const int chunk = step / ns, sl = step - chunk * ns;
+      const bool more = step + 1 < nsteps;
+      const bool new_chunk = more && sl == ns - 1;
+      if (more) w_issue(step + 1, wq[0]);
+      if (new_chunk) x_issue(chunk + 1);
+      const _Float16* Wc = Wb + (step & 1) * 2 * WIMG;
+      const int tap0 = sl * G;
+      const int nit = ((a.K - tap0) < G ? (a.K - tap0) : G) * KS;
+      if constexpr (PF) {
+        load_frags(Wc, tap0, 0, xhA, xlA, whA, wlA);
+        for (int it = 0; it < nit; it += 2) {
+          if (it + 1 < nit) load_frags(Wc, tap0, it + 1, xhB, xlB, whB, wlB);
+          mma(xhA, xlA, whA, wlA);
+          if (it + 1 < nit) {
+            if (it + 2 < nit) load_frags(Wc, tap0, it + 2, xhA, xlA, whA, wlA);
+            mma(xhB, xlB, whB, wlB);
+          }
+        }
+      } else {
+        for (int it = 0; it < nit; ++it) {
+          load_frags(Wc, tap0, it, xhA, xlA, whA, wlA);
+          mma(xhA, xlA, whA, wlA);
+        }
+      }
+      if (more) {
+        if (new_chunk) {
+          __syncthreads();
+          x_write();
+        }
+        w_write((step + 1) & 1, wq[0]);
+        __syncthreads();
+      }
+    }
+  } else if constexpr (WD == 2) {
+    for (int step = 0; step < nsteps; step += 2) {
+      step_body(step, wq[0], wq[1]);
+      if (step + 1 < nsteps) step_body(step + 1, wq[1], wq[0]);
+    }
+  } else {
+    for (int step = 0; step < nsteps; step += 3) {
+      step_body(step, wq[0], wq[1]);
+      if (step + 1 < nsteps) step_body(step + 1, wq[1], wq[2]);
+      if (step + 2 < nsteps) step_body(step + 2, wq[2], wq[0]);
     }
   }
 
@@ -288,7 +362,7 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
       float v[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] = hh[mt][nt][r] + cr[mt][nt][r] * (1.f / 2048.f);
-      if (a.res) {
+      if (a.res && (VSP_DIAG & 8) == 0) {
         float rv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r)
@@ -296,7 +370,7 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] += rv[r];
       }
-      if (a.acc_prev) {
+      if (a.acc_prev && (VSP_DIAG & 8) == 0) {
         float pv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r)
@@ -308,14 +382,21 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] /= a.div;
       }
+      if constexpr ((VSP_DIAG & 8) != 0) {
+        float sum = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), ro, lo + ((r & 3) + 8 * (r >> 2)) * ostep, 0, 0);
+        for (int r = 0; r < 16; ++r) sum += v[r];
+        if (sum == 1.2345e-30f) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sum), ro, lo, 0, 0);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), ro, lo + ((r & 3) + 8 * (r >> 2)) * ostep, 0, 0);
+      }
     }
   }
 }
 
-template <int MT, int NT, int WM, int WN, int CKC, int G, bool PF>
+template <int MT, int NT, int WM, int WN, int CKC, int G, bool PF, int WD>
 static hipError_t launch_cl_tile(const ClConvArgs& a, int B, hipStream_t s) {
   constexpr int BT = 32 * MT * WM;
   constexpr int RPU = (64 * WM * WN) / (CKC / 4);
@@ -324,7 +405,7 @@ static hipError_t launch_cl_tile(const ClConvArgs& a, int B, hipStream_t s) {
                          sizeof(_Float16);
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
-  auto kern = cl_conv_f16s<MT, NT, WM, WN, CKC, G, PF>;
+  auto kern = cl_conv_f16s<MT, NT, WM, WN, CKC, G, PF, WD>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -347,9 +428,9 @@ hipError_t launch_cl_conv(const ClConvArgs& a, int B, hipStream_t s) {
   //    (2 blocks of 4 waves, or fragment prefetch at 256 VGPRs, were both slower);
   //  * 64 / 32 output channels: LDS kept under 80 KiB (32-channel chunks, small weight ring) so that
   //    TWO blocks share a CU and overlap each other's load / MFMA / store phases.
-  if (a.Cout % 128 == 0 && a.Cin % 64 == 0) return launch_cl_tile<2, 2, 4, 2, 64, 1, false>(a, B, s);
-  if (a.Cout % 64 == 0) return launch_cl_tile<2, 1, 4, 2, 32, 1, true>(a, B, s);
-  return launch_cl_tile<1, 1, 8, 1, 32, 2, true>(a, B, s);
+  if (a.Cout % 128 == 0 && a.Cin % 64 == 0) return launch_cl_tile<2, 2, 4, 2, 64, 1, false, 2>(a, B, s);
+  if (a.Cout % 64 == 0) return launch_cl_tile<2, 1, 4, 2, 32, 1, true, 1>(a, B, s);
+  return launch_cl_tile<1, 1, 8, 1, 32, 2, true, 1>(a, B, s);
 }
 
 // ------------------------------------------------------------------------------------------
