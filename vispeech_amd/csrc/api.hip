@@ -349,17 +349,35 @@ void run_generator_cl(Run& r, int B, int T, T3 z, const int64_t* in_lengths, con
     int fb[4], nf = 0;
     for (int k = 0; k < 5; ++k) if (k != cur) fb[nf++] = k;
     float *XU = buf[fb[0]], *T1 = buf[fb[1]], *YA = buf[fb[2]], *XS = buf[fb[3]];
-    const long bs = Tout * ch;
-    r.clconv(U, buf[cur], Tn * cin, XU, bs, nullptr, 0, (int)Tn, (int)Tn + 1, (int)Tout, 0.1f, false, 1.f, B);
-    for (int j = 0; j < nk; ++j) {
-      const ResBlockW& rb = m.rbs[i * nk + j];
-      const int nd = (int)rb.dil.size();
-      for (int d = 0; d < nd; ++d) {
-        const float* yin = d == 0 ? XU : YA;
-        r.clconv(rb.h1[d], yin, bs, T1, bs, nullptr, 0, (int)Tout, (int)Tout, (int)Tout, 0.1f, false, 1.f, B);
-        const bool last = d == nd - 1;
-        r.clconv(rb.h2[d], T1, bs, last ? XS : YA, bs, yin, bs, (int)Tout, (int)Tout, (int)Tout, 0.1f, last && j > 0,
-                 (last && j == nk - 1) ? (float)nk : 1.f, B);
+    const long bs = Tout * ch, xbs = Tn * cin;
+    // Optional cache blocking over the batch (VSP_CHUNK_MB, default off): a stage runs chunk by chunk
+    // so that the tensors two consecutive launches exchange are <= chunk_mb and could be served by the
+    // 256 MiB Infinity Cache.  Measured on MI355X (profiles/r01_tile_experiments.txt): 32-192 MiB
+    // chunks are 3-10 % SLOWER than whole-batch launches (more launches and tails, no shorter kernels),
+    // so the product runs whole-batch; the knob stays for experiments.
+    int Bc = B;
+    if (r.ctx->chunk_mb > 0) {
+      const double per_utt_mb = (double)bs * 4.0 / (1024.0 * 1024.0);
+      Bc = (int)std::max(1.0, std::floor(r.ctx->chunk_mb / per_utt_mb));
+      const long tiles_per_utt = (Tout + 255) / 256 * std::max(1, ch / 128);
+      const int min_b = (int)((2 * 256 * (ch >= 128 ? 1 : 2) + tiles_per_utt - 1) / tiles_per_utt);
+      Bc = std::min(B, std::max(Bc, min_b));
+    }
+    for (int b0 = 0; b0 < B; b0 += Bc) {
+      const int nb = std::min(Bc, B - b0);
+      const float* xin = buf[cur] + (size_t)b0 * xbs;
+      float *xu = XU + (size_t)b0 * bs, *t1 = T1 + (size_t)b0 * bs, *ya = YA + (size_t)b0 * bs, *xs = XS + (size_t)b0 * bs;
+      r.clconv(U, xin, xbs, xu, bs, nullptr, 0, (int)Tn, (int)Tn + 1, (int)Tout, 0.1f, false, 1.f, nb);
+      for (int j = 0; j < nk; ++j) {
+        const ResBlockW& rb = m.rbs[i * nk + j];
+        const int nd = (int)rb.dil.size();
+        for (int d = 0; d < nd; ++d) {
+          const float* yin = d == 0 ? xu : ya;
+          r.clconv(rb.h1[d], yin, bs, t1, bs, nullptr, 0, (int)Tout, (int)Tout, (int)Tout, 0.1f, false, 1.f, nb);
+          const bool last = d == nd - 1;
+          r.clconv(rb.h2[d], t1, bs, last ? xs : ya, bs, yin, bs, (int)Tout, (int)Tout, (int)Tout, 0.1f,
+                   last && j > 0, (last && j == nk - 1) ? (float)nk : 1.f, nb);
+        }
       }
     }
     cur = fb[3];
@@ -405,6 +423,7 @@ int vsp_create(const vsp_config* cfg, int device, vsp_ctx** out) {
   if (const char* e = getenv("VSP_GENERATOR")) {
     if (!strcmp(e, "f32")) ctx->gen_mode = 0;
   }
+  if (const char* e = getenv("VSP_CHUNK_MB")) ctx->chunk_mb = atof(e);
   *out = ctx;  // returned even on failure so that vsp_last_error can be read; caller destroys it
   return rc;
 }

@@ -95,6 +95,7 @@ struct vsp_ctx {
   bool arena_owned = false;
   bool ready = false;
   int gen_mode = 1;  // 0: f32 MFMA channel-major generator, 1: split-f16 MFMA channels-last generator
+  double chunk_mb = 0.0;   // generator batch chunk in MiB per activation tensor (VSP_CHUNK_MB; 0 = whole batch: measured faster)
   // profiling of the dominant kernel
   bool prof_on = false;
   std::vector<hipEvent_t> ev_pool;
