@@ -37,8 +37,7 @@ struct ConvArgs {
   int ups_s, ups_p, T_store;  // transposed-conv store: row=(co,r), n = s*q + r - p in [0,T_store)
 };
 
-struct ConvShape { int bm, bn; };
-// tile: 0 = auto (chosen from M and Nq)
+// the tile shape is chosen from M and Nq
 hipError_t launch_conv(const ConvArgs& a, int B, hipStream_t s);
 size_t packed_conv_floats(int M, int Cin, int K);
 // W(row, ci, tap) accessor -> packed buffer (host).  dst has packed_conv_floats(M,Cin,K) floats.

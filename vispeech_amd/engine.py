@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .schema import ModelDims, used_by_infer
+from .schema import ModelDims
 
 
 def _ptr(t: Optional[torch.Tensor]):
