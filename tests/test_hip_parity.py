@@ -295,3 +295,14 @@ def test_long_form_60s_properties(net):
     o_cut = net._engine.generator(z[:, :, :1100].contiguous(), g)
     n = 512 * 1000
     assert torch.equal(o[:, :, :n], o_cut[:, :, :n])
+
+
+def test_streamed_vocoder_is_bit_identical(net, weights):
+    """Chunked generator with the 13-frame halo == one full call (streamed long-form synthesis)."""
+    rng = np.random.Generator(np.random.PCG64(9))
+    z = rng.standard_normal((1, 192, 700), dtype=np.float32)
+    gvec = weights["emb_g.weight"][[3]]
+    full = net._engine.generator(z, gvec)
+    parts = list(net._engine.generator_stream(z, gvec, chunk_frames=192))
+    assert len(parts) == 4 and parts[0].shape[-1] == 192 * 512
+    assert torch.equal(torch.cat(parts, dim=-1), full)

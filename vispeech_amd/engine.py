@@ -223,6 +223,23 @@ class Engine:
         _lib.check(rc, self.ctx, "vsp_generator")
         return o
 
+    GENERATOR_HALO = 13   # frames: the generator's receptive field is +-12.33 frames
+
+    def generator_stream(self, z, g, chunk_frames: int = 256):
+        """Streamed vocoder (BASELINE config 5): yields the waveform of ``z`` [B][C][T] chunk by chunk
+        ([B,1,512*n] tensors) so that the first audio is available after one chunk instead of after
+        the whole utterance.  Each chunk runs the generator on its frames plus a 13-frame halo on
+        both sides (zero padding only at the true ends), so the concatenation is bit-identical to
+        one ``generator(z, g)`` call."""
+        z = _dev_f32(z, self.device)
+        T = z.shape[2]
+        up, halo = self.dims.total_upsample, self.GENERATOR_HALO
+        for f0 in range(0, T, chunk_frames):
+            f1 = min(T, f0 + chunk_frames)
+            lo, hi = max(0, f0 - halo), min(T, f1 + halo)
+            o = self.generator(z[:, :, lo:hi].contiguous(), g)
+            yield o[:, :, (f0 - lo) * up:(f1 - lo) * up]
+
     def profile(self, on: bool) -> None:
         _lib.check(self.lib.vsp_profile_enable(self.ctx, int(on)), self.ctx, "vsp_profile_enable")
 
