@@ -306,3 +306,63 @@ def test_streamed_vocoder_is_bit_identical(net, weights):
     parts = list(net._engine.generator_stream(z, gvec, chunk_frames=192))
     assert len(parts) == 4 and parts[0].shape[-1] == 192 * 512
     assert torch.equal(torch.cat(parts, dim=-1), full)
+
+
+@pytest.mark.parametrize("frames", [1, 2, 13, 31, 33, 64, 127, 257])
+def test_generator_edge_lengths_match_oracle(net, oracle, weights, dims, frames):
+    """Tile-edge and degenerate lengths of the vocoder (shorter than the receptive field, one frame,
+    one past a tile boundary) against the CPU oracle's Generator.forward."""
+    from oracle.vispeech_oracle import generator as oracle_generator
+    rng = np.random.Generator(np.random.PCG64(1000 + frames))
+    z = rng.standard_normal((2, 192, frames), dtype=np.float32)
+    sid = np.array([5, 41])
+    gvec = weights["emb_g.weight"][sid]
+    o = net._engine.generator(z, gvec)
+    ref = oracle_generator(oracle.w, torch.from_numpy(z), torch.from_numpy(gvec)[:, :, None], dims)
+    assert o.shape == ref.shape == (2, 1, 512 * frames)
+    e = rel_err(to_np(o), ref.numpy())
+    assert e <= WAVE_TOL, (frames, e)
+
+
+def test_degenerate_batches(net, oracle):
+    """Single phoneme, zero-length phonemes in the middle, an utterance that is all padding but one
+    frame, and max_len larger than the batch: outputs match the oracle."""
+    dev = net.device
+    t = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
+    ph = np.array([[7, 0, 0, 0], [9, 15, 3, 200]], dtype=np.int64)
+    ln = np.array([1, 4], dtype=np.int64)
+    sid = np.array([0, 66], dtype=np.int64)
+    dur = np.array([[1, 0, 0, 0], [3, 0, 5, 2]], dtype=np.float32)
+    f0 = np.array([[220, 0, 0, 0], [0, 180, 300, 150]], dtype=np.float32)
+    en = np.array([[50, 0, 0, 0], [10, 20, 90, 60]], dtype=np.float32)
+    noise = np.random.Generator(np.random.PCG64(5)).standard_normal((2, 192, 10), dtype=np.float32)
+    ref = oracle.infer(ph, ln, sid, noise=noise, noise_scale=0.8, max_len=50, duration_control=dur, pitch_control=f0,
+                       energy_control=en)
+    o, x_mask, (z, *_), *_ = net.infer(t(ph), t(ln), sid=t(sid), noise_scale=0.8, max_len=50, duration_control=t(dur),
+                                       pitch_control=t(f0), energy_control=t(en), noise=t(noise))
+    np.testing.assert_array_equal(to_np(x_mask), ref["x_mask"].numpy())
+    assert x_mask.sum(dim=(1, 2)).tolist() == [1, 10]
+    assert rel_err(to_np(z), ref["z"].numpy()) <= STAGE_TOL
+    assert rel_err(to_np(o), ref["o"].numpy()) <= WAVE_TOL
+
+
+def test_abi_error_paths_on_device(net):
+    """Workspace too small, missing noise and bad arguments are reported as error codes, never crashes."""
+    from vispeech_amd import _lib
+    eng = net._engine
+    z = torch.zeros(1, 192, 8, device=net.device)
+    g = torch.zeros(1, 256, device=net.device)
+    o = torch.zeros(1, 1, 8 * 512, device=net.device)
+    ws = torch.zeros(1024, dtype=torch.uint8, device=net.device)
+    import ctypes as C
+    P = lambda x: C.c_void_p(x.data_ptr())
+    rc = eng.lib.vsp_generator(eng.ctx, None, 1, 8, P(z), P(g), P(o), P(ws), ws.numel())
+    assert rc == -6 and b"workspace" in eng.lib.vsp_last_error(eng.ctx)
+    rc = eng.lib.vsp_generator(eng.ctx, None, 0, 8, P(z), P(g), P(o), P(ws), ws.numel())
+    assert rc == -1
+    with pytest.raises(ValueError):
+        net.infer(torch.zeros(1, 3, dtype=torch.int64), torch.tensor([3]), sid=None)
+    with pytest.raises(_lib.VspError):
+        enc = eng.encode(torch.ones(1, 3, dtype=torch.int64), torch.tensor([3]), torch.tensor([1]),
+                         duration_ctl=torch.ones(1, 3), pitch_ctl=torch.ones(1, 3), energy_ctl=torch.ones(1, 3))
+        eng.decode(enc, 3, None, 0.5)          # noise required when noise_scale != 0

@@ -54,7 +54,7 @@ struct Run {
   int rc = VSP_OK;
   bool dry() const { return ws.dry; }
   const float* A(size_t off) const { return ctx->arena + off; }
-  bool ok() const { return rc == VSP_OK; }
+  bool ok() const { return rc == VSP_OK && !ws.overflow; }
   void chk(hipError_t e, const char* what) {
     if (e != hipSuccess && rc == VSP_OK) rc = ctx->fail(VSP_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
   }
@@ -548,7 +548,7 @@ static int encode_impl(vsp_ctx* ctx, hipStream_t s, Ws& ws, int B, int Tp, const
   // duration-predictor / energy-predictor activations
   const int fmax_ = std::max(c.dur_filter, c.energy_filter);
   T3 P1 = ws.t3(B, fmax_, Tp), P2 = ws.t3(B, fmax_, Tp);
-  const bool live = !ws.dry;
+  const bool live = !ws.dry && !ws.overflow;
   if (live) {
     r.chk(launch_gather_rows(sid, r.A(m.emb_g), c.n_speakers, g, B, gin, s), "emb_g");
     r.chk(launch_embed(phonemes, r.A(m.emb_sym), c.n_vocab, sqrtf((float)h), XE.p, XE.bs, XE.cs, B, h, Tp, s),
@@ -633,6 +633,9 @@ int vsp_encode(vsp_ctx* ctx, void* stream, int B, int Tp, const int64_t* phoneme
   if (B <= 0 || Tp <= 0 || !phonemes || !lengths || !sid || !x_var || !g || !duration || !f0 || !energy ||
       !frame_lengths || !cum_dur || !workspace)
     return ctx->fail(VSP_ERR_ARG, "vsp_encode: null or non-positive argument");
+  const int64_t need = vsp_encode_workspace_bytes(ctx, B, Tp);
+  if (workspace_bytes < need)
+    return ctx->fail(VSP_ERR_WORKSPACE, "encode workspace too small: %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
   Ws ws(workspace, (size_t)workspace_bytes, false);
   return encode_impl(ctx, (hipStream_t)stream, ws, B, Tp, phonemes, lengths, sid, duration_ctl, pitch_ctl, energy_ctl,
                      duration_scale, pitch_scale, energy_scale, x_var, g, duration, f0, energy, frame_lengths, cum_dur);
@@ -660,8 +663,8 @@ static int decode_impl(vsp_ctx* ctx, hipStream_t s, Ws& ws, int B, int Tp, int T
   const Model& m = ctx->model;
   const int h = c.hidden_channels, inter = c.inter_channels;
   Run r{ctx, s, ws};
-  const bool live = !ws.dry;
   T3 XF = ws.t3(B, h, Tf), HF = ws.t3(B, h, Tf);
+  const bool live = !ws.dry && !ws.overflow;
   if (live) {
     r.chk(launch_length_regulate(x_var, (long)h * Tp, Tp, cum_dur, XF.p, XF.bs, XF.cs, B, h, Tp, Tf, s), "length_regulate");
     r.chk(launch_mask_u8(frame_lengths, x_mask, B, Tf, s), "x_mask");
@@ -704,6 +707,9 @@ int vsp_decode(vsp_ctx* ctx, void* stream, int B, int Tp, int Tf, int max_len, c
       !m_p || !logs_p || !workspace)
     return ctx->fail(VSP_ERR_ARG, "vsp_decode: null or non-positive argument");
   if (!noise && noise_scale != 0.f) return ctx->fail(VSP_ERR_ARG, "vsp_decode: noise is required when noise_scale != 0");
+  const int64_t need = vsp_decode_workspace_bytes(ctx, B, Tp, Tf);
+  if (workspace_bytes < need)
+    return ctx->fail(VSP_ERR_WORKSPACE, "decode workspace too small: %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
   Ws ws(workspace, (size_t)workspace_bytes, false);
   return decode_impl(ctx, (hipStream_t)stream, ws, B, Tp, Tf, max_len, x_var, g, cum_dur, frame_lengths, noise,
                      noise_scale, o, x_mask, z, z_p, m_p, logs_p);
@@ -725,6 +731,8 @@ int vsp_encoder(vsp_ctx* ctx, void* stream, int which, int B, int T, const float
   if (rc) return rc;
   if (which < 0 || which > 2 || B <= 0 || T <= 0 || !x || !lengths || !y || !workspace)
     return ctx->fail(VSP_ERR_ARG, "vsp_encoder: bad argument");
+  if (workspace_bytes < vsp_encoder_workspace_bytes(ctx, B, T))
+    return ctx->fail(VSP_ERR_WORKSPACE, "encoder workspace too small");
   Ws ws(workspace, (size_t)workspace_bytes, false);
   Run r{ctx, (hipStream_t)stream, ws};
   const int h = ctx->cfg.hidden_channels;
@@ -761,6 +769,8 @@ int vsp_flow_reverse(vsp_ctx* ctx, void* stream, int B, int Tf, const float* z_p
   if (rc) return rc;
   if (B <= 0 || Tf <= 0 || !z_p || !g || !frame_lengths || !z || !workspace)
     return ctx->fail(VSP_ERR_ARG, "vsp_flow_reverse: bad argument");
+  if (workspace_bytes < vsp_flow_workspace_bytes(ctx, B, Tf))
+    return ctx->fail(VSP_ERR_WORKSPACE, "flow workspace too small");
   Ws ws(workspace, (size_t)workspace_bytes, false);
   Run r{ctx, (hipStream_t)stream, ws};
   const long n = (long)B * ctx->cfg.inter_channels * Tf;
@@ -783,6 +793,9 @@ int vsp_generator(vsp_ctx* ctx, void* stream, int B, int T, const float* z, cons
   int rc = check_ready(ctx);
   if (rc) return rc;
   if (B <= 0 || T <= 0 || !z || !g || !o || !workspace) return ctx->fail(VSP_ERR_ARG, "vsp_generator: bad argument");
+  if (workspace_bytes < vsp_generator_workspace_bytes(ctx, B, T))
+    return ctx->fail(VSP_ERR_WORKSPACE, "generator workspace too small (need %lld bytes)",
+                     (long long)vsp_generator_workspace_bytes(ctx, B, T));
   Ws ws(workspace, (size_t)workspace_bytes, false);
   Run r{ctx, (hipStream_t)stream, ws};
   run_gen(r, B, T, ext(z, ctx->cfg.inter_channels, T), nullptr, g, o);
