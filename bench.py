@@ -196,6 +196,11 @@ def main():
                          "alg_tflops": tfl, "alg_gbs": gbs, "hbm_frac": f_hbm, "mfma_issue_frac": f_mfma,
                          "note": "fp32 activations in HBM; f16 MFMA on split operands (3 MFMA per product), fp32-accurate"})
             dtype = "f32 (split-f16 MFMA, 3-term)"
+            if gen_mode == "f16":      # opt-in reduced precision: NOT the headline configuration
+                dtype = "f16 operands, f32 accumulate (VSP_GENERATOR=f16: reduced precision, fails the fp32 parity gate)"
+                f_mfma = tfl / PEAK_F16_MFMA_TFLOPS
+                roof["mfma_issue_frac"] = f_mfma
+                roof["note"] = "fp32 activations in HBM; plain f16 MFMA operands (1 MFMA per product)"
         traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(traffic_file):
             try:

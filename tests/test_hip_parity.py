@@ -366,3 +366,23 @@ def test_abi_error_paths_on_device(net):
         enc = eng.encode(torch.ones(1, 3, dtype=torch.int64), torch.tensor([3]), torch.tensor([1]),
                          duration_ctl=torch.ones(1, 3), pitch_ctl=torch.ones(1, 3), energy_ctl=torch.ones(1, 3))
         eng.decode(enc, 3, None, 0.5)          # noise required when noise_scale != 0
+
+
+def test_reduced_precision_mode_is_opt_in_and_gated(dims, weights, golden_dir, monkeypatch):
+    """VSP_GENERATOR=f16 (plain f16 operands, one MFMA per product: the low-precision variant of
+    BASELINE config 3) is NOT the product default; it must still reach >= 30 dB SNR against the
+    reference waveform -- and it must NOT pass the fp32 gate by accident."""
+    monkeypatch.setenv("VSP_GENERATOR", "f16")
+    from vispeech_amd import config as vcfg
+    from vispeech_amd.models import SynthesizerTrn
+    args, kwargs = vcfg.synthesizer_args(vcfg.default_hparams())
+    m = SynthesizerTrn(*args, **kwargs).eval()
+    m.load_state_dict(weights, strict=True)
+    g = golden(golden_dir, "ragged_controls")
+    o = to_np(run_case(m, g)[0]).astype(np.float64)
+    ref = g["o"].astype(np.float64)
+    snr = 10 * np.log10((ref ** 2).sum() / ((o - ref) ** 2).sum())
+    e = rel_err(o, ref)
+    print(f"f16 generator: SNR {snr:.1f} dB, max rel err {e:.2e}")
+    assert snr >= 30.0
+    assert e > 1e-5          # i.e. really the reduced-precision path

@@ -112,6 +112,7 @@ struct Run {
     a.in_act = 1; a.in_slope = in_slope;
     a.acc_prev = acc_prev ? 1 : 0; a.div = div;
     a.phases = L.phases; a.ups_p = L.ups_p; a.T_store = T_store;
+    a.terms = ctx->gen_mode == 2 ? 1 : 3;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->prof_on) {
       while (ctx->ev_pool.size() < ctx->ev_used + 2) {
@@ -389,7 +390,7 @@ void run_generator_cl(Run& r, int B, int T, T3 z, const int64_t* in_lengths, con
 }
 
 void run_gen(Run& r, int B, int T, T3 z, const int64_t* in_lengths, const float* g, float* o) {
-  if (r.ctx->gen_mode == 1 && r.ctx->model.has_cl) run_generator_cl(r, B, T, z, in_lengths, g, o);
+  if (r.ctx->gen_mode >= 1 && r.ctx->model.has_cl) run_generator_cl(r, B, T, z, in_lengths, g, o);
   else run_generator(r, B, T, z, in_lengths, g, o);
 }
 
@@ -422,6 +423,7 @@ int vsp_create(const vsp_config* cfg, int device, vsp_ctx** out) {
   const int rc = plan_model(ctx);
   if (const char* e = getenv("VSP_GENERATOR")) {
     if (!strcmp(e, "f32")) ctx->gen_mode = 0;
+    if (!strcmp(e, "f16") && ctx->gen_mode == 1) ctx->gen_mode = 2;   // opt-in reduced precision
   }
   if (const char* e = getenv("VSP_CHUNK_MB")) ctx->chunk_mb = atof(e);
   *out = ctx;  // returned even on failure so that vsp_last_error can be read; caller destroys it

@@ -76,7 +76,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define VSP_DIAG 0
 #endif
 
-template <int MT, int NT, int WM, int WN, int CKC, int G, bool PF, int WD>
+// TERMS = 3: fp32-accurate split product (default).  TERMS = 1: plain f16 operands (hi images only,
+// one MFMA per product) -- the opt-in reduced-precision mode VSP_GENERATOR=f16 (BASELINE config 3's
+// low-precision variant), NOT used by bench.py or the parity gates.
+template <int MT, int NT, int WM, int WN, int CKC, int G, bool PF, int WD, int TERMS>
 __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
   constexpr int BT = 32 * MT * WM;
   constexpr int RS = CKC + 8;                 // LDS row stride of the activation images (halfs)
@@ -90,7 +93,7 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
   constexpr int XIMG = WMAX * RS;             // halfs per activation image
   constexpr int WIMG = G * KS * NTB * 64 * 8; // halfs per weight-slice image
   constexpr int NWV = NTH / 64;
-  constexpr int NBLK = 2 * G * KS * NTB;      // 1-KiB fragment blocks per slice (hi + lo)
+  constexpr int NBLK = (TERMS == 3 ? 2 : 1) * G * KS * NTB;   // 1-KiB fragment blocks per slice (hi [+ lo])
   constexpr int NWL = (NBLK + NWV - 1) / NWV; // blocks per wave per slice
   extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
   _Float16* const Xh = lds;                   // [WMAX][RS] hi, then lo
@@ -168,7 +171,7 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
       }
       _Float16* dst = Xh + st_loff + u * (ROWS_PER_U * RS);  // compile-time stride
       *reinterpret_cast<f16x4*>(dst) = eh;
-      *reinterpret_cast<f16x4*>(dst + XIMG) = el;
+      if constexpr (TERMS == 3) *reinterpret_cast<f16x4*>(dst + XIMG) = el;
     }
   };
   // ---- weight-slice staging: slice (chunk, sl) = taps [sl*G, sl*G+G) x k-steps of the chunk x the
@@ -211,13 +214,13 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       xh[mt] = *reinterpret_cast<const f16x8*>(px + mt * 32 * RS);
-      xl[mt] = *reinterpret_cast<const f16x8*>(px + mt * 32 * RS + XIMG);
+      if constexpr (TERMS == 3) xl[mt] = *reinterpret_cast<const f16x8*>(px + mt * 32 * RS + XIMG);
     }
     const _Float16* pw = Wc + wf_lane + (g * KS + ks) * NTB * 512;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       wh[nt] = *reinterpret_cast<const f16x8*>(pw + nt * 512);
-      wl[nt] = *reinterpret_cast<const f16x8*>(pw + nt * 512 + WIMG);
+      if constexpr (TERMS == 3) wl[nt] = *reinterpret_cast<const f16x8*>(pw + nt * 512 + WIMG);
     }
   };
   auto mma = [&](const f16x8(&xh)[MT], const f16x8(&xl)[MT], const f16x8(&wh)[NT], const f16x8(&wl)[NT]) {
@@ -235,16 +238,18 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
         hh[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[mt], wh[nt], hh[mt][nt], 0, 0, 0);
+    if constexpr (TERMS == 3) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        cr[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[mt], wl[nt], cr[mt][nt], 0, 0, 0);
+        for (int nt = 0; nt < NT; ++nt)
+          cr[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[mt], wl[nt], cr[mt][nt], 0, 0, 0);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        cr[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[mt], wh[nt], cr[mt][nt], 0, 0, 0);
+        for (int nt = 0; nt < NT; ++nt)
+          cr[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[mt], wh[nt], cr[mt][nt], 0, 0, 0);
+    }
   };
 
   x_issue(0);
@@ -396,7 +401,7 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
   }
 }
 
-template <int MT, int NT, int WM, int WN, int CKC, int G, bool PF, int WD>
+template <int MT, int NT, int WM, int WN, int CKC, int G, bool PF, int WD, int TERMS>
 static hipError_t launch_cl_tile(const ClConvArgs& a, int B, hipStream_t s) {
   constexpr int BT = 32 * MT * WM;
   constexpr int RPU = (64 * WM * WN) / (CKC / 4);
@@ -405,7 +410,7 @@ static hipError_t launch_cl_tile(const ClConvArgs& a, int B, hipStream_t s) {
                          sizeof(_Float16);
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
-  auto kern = cl_conv_f16s<MT, NT, WM, WN, CKC, G, PF, WD>;
+  auto kern = cl_conv_f16s<MT, NT, WM, WN, CKC, G, PF, WD, TERMS>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -428,9 +433,14 @@ hipError_t launch_cl_conv(const ClConvArgs& a, int B, hipStream_t s) {
   //    (2 blocks of 4 waves, or fragment prefetch at 256 VGPRs, were both slower);
   //  * 64 / 32 output channels: LDS kept under 80 KiB (32-channel chunks, small weight ring) so that
   //    TWO blocks share a CU and overlap each other's load / MFMA / store phases.
-  if (a.Cout % 128 == 0 && a.Cin % 64 == 0) return launch_cl_tile<2, 2, 4, 2, 64, 1, false, 2>(a, B, s);
-  if (a.Cout % 64 == 0) return launch_cl_tile<2, 1, 4, 2, 32, 1, true, 1>(a, B, s);
-  return launch_cl_tile<1, 1, 8, 1, 32, 2, true, 1>(a, B, s);
+  if (a.terms == 1) {
+    if (a.Cout % 128 == 0 && a.Cin % 64 == 0) return launch_cl_tile<2, 2, 4, 2, 64, 1, false, 2, 1>(a, B, s);
+    if (a.Cout % 64 == 0) return launch_cl_tile<2, 1, 4, 2, 32, 1, true, 1, 1>(a, B, s);
+    return launch_cl_tile<1, 1, 8, 1, 32, 2, true, 1, 1>(a, B, s);
+  }
+  if (a.Cout % 128 == 0 && a.Cin % 64 == 0) return launch_cl_tile<2, 2, 4, 2, 64, 1, false, 2, 3>(a, B, s);
+  if (a.Cout % 64 == 0) return launch_cl_tile<2, 1, 4, 2, 32, 1, true, 1, 3>(a, B, s);
+  return launch_cl_tile<1, 1, 8, 1, 32, 2, true, 1, 3>(a, B, s);
 }
 
 // ------------------------------------------------------------------------------------------

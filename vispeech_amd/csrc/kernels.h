@@ -56,6 +56,7 @@ struct ClConvArgs {
   int in_act; float in_slope;
   int acc_prev; float div;
   int phases, ups_p, T_store;               // polyphase transposed conv: row n = phases*q + ph - ups_p
+  int terms;                                // 3 = fp32-accurate split product (default), 1 = plain f16 operands
 };
 hipError_t launch_cl_conv(const ClConvArgs& a, int B, hipStream_t s);
 size_t packed_cl_halfs(int Cout, int Cin, int K, int phases);

@@ -94,7 +94,8 @@ struct vsp_ctx {
   float* arena = nullptr;
   bool arena_owned = false;
   bool ready = false;
-  int gen_mode = 1;  // 0: f32 MFMA channel-major generator, 1: split-f16 MFMA channels-last generator
+  int gen_mode = 1;  // 0: f32 MFMA channel-major generator, 1: split-f16 (fp32-accurate) channels-last generator,
+                     // 2: same kernels with plain f16 operands (VSP_GENERATOR=f16, opt-in reduced precision)
   double chunk_mb = 0.0;   // generator batch chunk in MiB per activation tensor (VSP_CHUNK_MB; 0 = whole batch: measured faster)
   // profiling of the dominant kernel
   bool prof_on = false;
