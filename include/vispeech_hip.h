@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define VSP_ABI_VERSION 1
+#define VSP_ABI_VERSION 2
 
 enum {
   VSP_OK = 0,
@@ -72,6 +72,11 @@ typedef struct vsp_config {
   int32_t flow_kernel;
   int32_t flow_layers;
   int32_t n_flows;
+  /* voice conversion only (ABI 2): input channels of the posterior encoder = filter_length/2+1
+   * (reference models.py:596) and its WN depth (16, models.py:596).  spec_channels == 0 builds a
+   * context without the posterior encoder (enc_q.* tensors are then accepted and ignored). */
+  int32_t spec_channels;
+  int32_t posterior_layers;
 } vsp_config;
 
 typedef struct vsp_ctx vsp_ctx;
@@ -156,6 +161,29 @@ int vsp_flow_reverse(vsp_ctx* ctx, void* stream, int B, int Tf, const float* z_p
 int64_t vsp_generator_workspace_bytes(const vsp_ctx* ctx, int B, int T);
 int vsp_generator(vsp_ctx* ctx, void* stream, int B, int T, const float* z, const float* g,
                   float* o, void* workspace, int64_t workspace_bytes);
+
+/* ---- voice conversion: replaces SynthesizerTrn.voice_conversion (reference models.py:724-732) */
+/* Needs cfg.spec_channels > 0 and every enc_q.* tensor set before vsp_finalize_weights
+ * (VSP_ERR_STATE otherwise).  y [B][spec][T] linear spectrogram, y_lengths[B], sid_src/sid_tgt[B]
+ * int64, noise [B][inter][T] (the torch.randn_like of models.py:230).  Outputs (device,
+ * contiguous): o_hat [B][1][T*prod(upsample_rates)], y_mask [B*T] uint8, z / z_p / z_hat
+ * [B][inter][T]; m_q / logs_q [B][inter][T] may be NULL. */
+int64_t vsp_voice_conversion_workspace_bytes(const vsp_ctx* ctx, int B, int T);
+int vsp_voice_conversion(vsp_ctx* ctx, void* stream, int B, int T, const float* y, const int64_t* y_lengths,
+                         const int64_t* sid_src, const int64_t* sid_tgt, const float* noise,
+                         float* o_hat, uint8_t* y_mask, float* z, float* z_p, float* z_hat,
+                         float* m_q, float* logs_q, void* workspace, int64_t workspace_bytes);
+/* PosteriorEncoder.forward (reference models.py:212-241): y, lengths, g [B][gin], noise -> z, m, logs. */
+int64_t vsp_posterior_workspace_bytes(const vsp_ctx* ctx, int B, int T);
+int vsp_posterior_encoder(vsp_ctx* ctx, void* stream, int B, int T, const float* y, const int64_t* y_lengths,
+                          const float* g, const float* noise, float* z, float* m, float* logs,
+                          void* workspace, int64_t workspace_bytes);
+/* ResidualCouplingBlock.forward(reverse=False) (reference models.py:202-206). z -> z_p. */
+int vsp_flow_forward(vsp_ctx* ctx, void* stream, int B, int Tf, const float* z, const float* g,
+                     const int64_t* frame_lengths, float* z_p, void* workspace, int64_t workspace_bytes);
+/* 1 if the posterior-encoder weights are loaded (voice conversion available), else 0. */
+int vsp_has_voice_conversion(const vsp_ctx* ctx);
+
 /* piecewise_rational_quadratic_transform with tails='linear' (reference transforms.py:12-193),
  * n elements, nb bins; uw/uh [n][nb], ud [n][nb-1]; outputs y[n], logabsdet[n]. */
 int vsp_rq_spline(void* stream, int64_t n, int nb, const float* x, const float* uw, const float* uh,

@@ -218,6 +218,32 @@ def flow_reverse(w, z, mask_f, g, dims):
     return x
 
 
+def flow_forward(w, z, mask_f, g, dims):
+    """ResidualCouplingBlock.forward(reverse=False) (reference models.py:202-206): coupling
+    (modules.py:324-340, mean_only so logs = 0) then Flip (modules.py:270-274), layers 0 .. n-1."""
+    half = dims.inter_channels // 2
+    x = z
+    for i in range(dims.n_flows):
+        p = f"flow.flows.{2 * i}"
+        x0, x1 = x[:, :half], x[:, half:]
+        h = F.conv1d(x0, w[f"{p}.pre.weight"], w[f"{p}.pre.bias"]) * mask_f
+        h = wn(w, f"{p}.enc", h, mask_f, g, dims.hidden_channels, dims.flow_layers, dims.flow_kernel)
+        m = F.conv1d(h, w[f"{p}.post.weight"], w[f"{p}.post.bias"]) * mask_f
+        x1 = m + x1 * mask_f
+        x = torch.flip(torch.cat([x0, x1], dim=1), [1])
+    return x
+
+
+def posterior_encoder(w, y, mask_f, g, noise, dims):
+    """PosteriorEncoder.forward (reference models.py:233-241): returns z, m, logs."""
+    x = F.conv1d(y, w["enc_q.pre.weight"], w["enc_q.pre.bias"]) * mask_f
+    x = wn(w, "enc_q.enc", x, mask_f, g, dims.hidden_channels, dims.posterior_layers, dims.flow_kernel)
+    stats = F.conv1d(x, w["enc_q.proj.weight"], w["enc_q.proj.bias"]) * mask_f
+    m, logs = stats[:, :dims.inter_channels], stats[:, dims.inter_channels:]
+    z = (m + noise * torch.exp(logs)) * mask_f
+    return z, m, logs
+
+
 def generator(w, x, g, dims):
     """Generator.forward (reference models.py:271-290) with ResBlock1 (modules.py:210-223)."""
     x = F.conv1d(x, w["dec.conv_pre.weight"], w["dec.conv_pre.bias"], padding=3)
@@ -339,6 +365,26 @@ class Oracle:
 
 
 # --------------------------------------------------------------------------- spline
+def _vc(self, y, y_lengths, sid_src, sid_tgt, noise):
+    """SynthesizerTrn.voice_conversion (reference models.py:724-732)."""
+    w, d = self.w, self.dims
+    y = torch.as_tensor(y, dtype=self.dtype)
+    y_lengths = torch.as_tensor(y_lengths, dtype=torch.int64)
+    g_src = w["emb_g.weight"][torch.as_tensor(sid_src, dtype=torch.int64)][:, :, None]
+    g_tgt = w["emb_g.weight"][torch.as_tensor(sid_tgt, dtype=torch.int64)][:, :, None]
+    mask = sequence_mask(y_lengths, y.shape[2])
+    m = mask.to(self.dtype)[:, None, :]
+    noise = torch.as_tensor(noise, dtype=self.dtype)
+    z, m_q, logs_q = posterior_encoder(w, y, m, g_src, noise, d)
+    z_p = flow_forward(w, z, m, g_src, d)
+    z_hat = flow_reverse(w, z_p, m, g_tgt, d)
+    o_hat = generator(w, z_hat * m, g_tgt, d)
+    return dict(o_hat=o_hat, y_mask=m, z=z, z_p=z_p, z_hat=z_hat, m_q=m_q, logs_q=logs_q)
+
+
+Oracle.voice_conversion = torch.no_grad()(_vc)
+
+
 def rq_spline(inputs, uw, uh, ud, inverse=False, tail_bound=5.0, min_bin_width=1e-3,
               min_bin_height=1e-3, min_derivative=1e-3):
     """Unconstrained (linear-tail) monotone rational-quadratic spline of reference

@@ -164,21 +164,54 @@ def filelist_case(net):
     run_case(net, "c1_filelist", batch)
 
 
+def vc_case(net, dims):
+    """SynthesizerTrn.voice_conversion (reference models.py:724-732) on a ragged batch of synthetic
+    linear spectrograms (|N(0,1)| magnitudes, the scale of spectrogram_torch output on speech)."""
+    r = np.random.Generator(np.random.PCG64(2024))
+    lens = np.array([21, 30, 9], dtype=np.int64)
+    B, T = len(lens), int(lens.max())
+    y = np.abs(r.standard_normal((B, dims.spec_channels, T))).astype(np.float32)
+    for b, n in enumerate(lens):
+        y[b, :, n:] = 0.0
+    sid_src = np.array([3, 17, 40], dtype=np.int64)
+    sid_tgt = np.array([8, 17, 2], dtype=np.int64)
+    noise = r.standard_normal((B, dims.inter_channels, T)).astype(np.float32)
+    stages = {}
+    h = net.enc_q.register_forward_hook(lambda _m, _i, out: stages.update(m_q=out[1].detach().numpy().copy(),
+                                                                          logs_q=out[2].detach().numpy().copy()))
+    with torch.no_grad(), _Noise(noise):
+        o_hat, y_mask, (z, z_p, z_hat) = net.voice_conversion(
+            torch.from_numpy(y), torch.from_numpy(lens), torch.from_numpy(sid_src), torch.from_numpy(sid_tgt))
+    h.remove()
+    path = os.path.join(HERE, "voice_conversion.npz")
+    np.savez_compressed(path, in_y=y, in_lengths=lens,
+                        in_sid_src=sid_src, in_sid_tgt=sid_tgt, in_noise=noise, o_hat=o_hat.numpy(),
+                        y_mask=y_mask.numpy(), z=z.numpy(), z_p=z_p.numpy(), z_hat=z_hat.numpy(), **stages)
+    print(f"voice_conversion: B={B} T={T} |o|max={np.abs(o_hat.numpy()).max():.4f} |z_p|max={np.abs(z_p.numpy()).max():.3f}"
+          f" -> {os.path.getsize(path)/1024:.0f} KiB")
+
+
 def main():
+    """``make_golden.py`` rewrites everything; ``make_golden.py vc`` only voice_conversion.npz."""
     torch.manual_seed(0)
     torch.set_num_threads(8)
     net, dims = build_reference()
-    # ragged batch, controls supplied (the throughput configuration)
-    b3 = synth_batch(3, seed=11, mean_phonemes=9, std_phonemes=3, min_phonemes=5, max_phonemes=12,
-                     mean_frames=34, jitter_frames=6)
-    run_case(net, "ragged_controls", b3)
-    # same inputs, every predictor on (scalar controls), durations predicted
-    run_case(net, "ragged_predictors", b3, use_duration=False, use_pitch=False, use_energy=False,
-             scalar_controls=dict(duration=0.25, pitch=1.1, energy=0.9), noise_scale=0.5)
-    # max_len truncation + [B,1,Tp] duration tensor + pitch predicted only
-    run_case(net, "maxlen_dur3d", b3, use_pitch=False, max_len=20, dur_3d=True, noise_scale=1.0)
-    filelist_case(net)
-    spline_case()
+    only = set(sys.argv[1:])
+    if not only or "infer" in only:
+        # ragged batch, controls supplied (the throughput configuration)
+        b3 = synth_batch(3, seed=11, mean_phonemes=9, std_phonemes=3, min_phonemes=5, max_phonemes=12,
+                         mean_frames=34, jitter_frames=6)
+        run_case(net, "ragged_controls", b3)
+        # same inputs, every predictor on (scalar controls), durations predicted
+        run_case(net, "ragged_predictors", b3, use_duration=False, use_pitch=False, use_energy=False,
+                 scalar_controls=dict(duration=0.25, pitch=1.1, energy=0.9), noise_scale=0.5)
+        # max_len truncation + [B,1,Tp] duration tensor + pitch predicted only
+        run_case(net, "maxlen_dur3d", b3, use_pitch=False, max_len=20, dur_3d=True, noise_scale=1.0)
+        filelist_case(net)
+    if not only or "spline" in only:
+        spline_case()
+    if not only or "vc" in only:
+        vc_case(net, dims)
 
 
 if __name__ == "__main__":

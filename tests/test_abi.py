@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), s
     assert sorted(_lib.SIGNATURES) == syms, "ctypes signature table and header disagree"
-    assert lib.vsp_abi_version() == 1
+    assert lib.vsp_abi_version() == 2
 
 
 @pytest.fixture()
@@ -58,6 +58,30 @@ def test_schema_matches_python_schema(ctx):
     assert len(schema) == 753            # the reference's state_dict size
 
 
+def test_posterior_encoder_tensors_are_optional_but_validated(ctx):
+    """enc_q.* (voice conversion only) never counts as missing, but its shapes are checked when the
+    config names spec_channels; a context without spec_channels accepts and ignores them."""
+    lib, h = ctx
+    dims = ModelDims()
+    schema = state_dict_schema(dims)
+    for k, shape in schema.items():
+        if used_by_infer(k):
+            assert _set(lib, h, k, np.zeros(shape, dtype=np.float32)) == 0
+    assert lib.vsp_missing_weights(h) == 0                      # enc_q.* absent, nothing missing
+    assert _set(lib, h, "enc_q.pre.weight", np.zeros(schema["enc_q.pre.weight"])) == 0
+    assert _set(lib, h, "enc_q.pre.weight", np.zeros((192, 513, 1))) == -5
+    assert _set(lib, h, "enc_q.nonexistent", np.zeros((1,))) == -4
+    assert lib.vsp_has_voice_conversion(h) == 0                 # nothing finalised
+    cfg = _lib.make_config(dims)
+    cfg.spec_channels = 0
+    h2 = C.c_void_p()
+    assert lib.vsp_create(C.byref(cfg), 0, C.byref(h2)) == 0
+    assert _set(lib, h2, "enc_q.pre.weight", np.zeros((192, 513, 1))) == 0     # ignored
+    assert lib.vsp_voice_conversion_workspace_bytes(h2, 1, 16) > 0
+    assert lib.vsp_weight_arena_bytes(h2) < lib.vsp_weight_arena_bytes(h)
+    lib.vsp_destroy(h2)
+
+
 def test_bad_key_and_shape_are_rejected(ctx):
     lib, h = ctx
     assert _set(lib, h, "dec.nonexistent.weight", np.zeros((1,))) == -4
@@ -70,8 +94,9 @@ def test_bad_key_and_shape_are_rejected(ctx):
 def test_arena_and_workspace_sizes(ctx):
     lib, h = ctx
     arena = lib.vsp_weight_arena_bytes(h)
-    n_params = sum(int(np.prod(s)) for s in infer_schema(ModelDims()).values())
-    # packed arena holds every infer-path parameter (weight_g folded away, some zero padding)
+    n_params = sum(int(np.prod(s)) for k, s in state_dict_schema(ModelDims()).items()
+                   if used_by_infer(k) or k.startswith("enc_q."))
+    # packed arena holds every infer-path parameter and the posterior encoder (weight_g folded away, some zero padding)
     assert 0.9 * 4 * n_params < arena < 1.5 * 4 * n_params   # generator weights are held in both packings
     e1, e2 = lib.vsp_encode_workspace_bytes(h, 2, 40), lib.vsp_encode_workspace_bytes(h, 4, 40)
     assert 0 < e1 < e2

@@ -64,3 +64,19 @@ def test_spline_matches_reference(golden_dir):
     y, _ = rq_spline(g["x"], g["uw"], g["uh"], g["ud"], inverse=False)
     x2, _ = rq_spline(y, g["uw"], g["uh"], g["ud"], inverse=True)
     assert np.abs(x2.numpy() - g["x"]).max() <= 1e-3   # fp32 round trip (SURVEY: 3.6e-5 typical)
+
+
+def test_oracle_voice_conversion_matches_reference(golden_dir):
+    """SynthesizerTrn.voice_conversion (reference models.py:724-732): posterior encoder, flow forward
+    with the source speaker, flow reverse with the target speaker, generator."""
+    dims = ModelDims()
+    orc = Oracle(synth_state_dict(dims, seed=1234), dims)          # full checkpoint: enc_q.* included
+    g = np.load(os.path.join(golden_dir, "voice_conversion.npz"))
+    out = orc.voice_conversion(g["in_y"], g["in_lengths"], g["in_sid_src"], g["in_sid_tgt"], g["in_noise"])
+    np.testing.assert_array_equal(out["y_mask"].numpy(), g["y_mask"])
+    for name in ["m_q", "logs_q", "z", "z_p", "z_hat"]:
+        e = rel_err(out[name].numpy(), g[name])
+        assert e <= 1e-5, (name, e)
+    assert rel_err(out["o_hat"].numpy(), g["o_hat"]) <= 1e-4
+    # same speaker on both sides: the two flow passes cancel (row 1 has sid_src == sid_tgt)
+    assert np.abs(out["z_hat"][1].numpy() - out["z"][1].numpy()).max() <= 1e-4 * np.abs(g["z"][1]).max()

@@ -32,6 +32,7 @@ class VspConfig(C.Structure):
         ("n_speakers", C.c_int32), ("gin_channels", C.c_int32), ("window_size", C.c_int32),
         ("pitch_layers", C.c_int32), ("dur_filter", C.c_int32), ("energy_filter", C.c_int32),
         ("flow_kernel", C.c_int32), ("flow_layers", C.c_int32), ("n_flows", C.c_int32),
+        ("spec_channels", C.c_int32), ("posterior_layers", C.c_int32),
     ]
 
 
@@ -64,6 +65,12 @@ SIGNATURES = {
     "vsp_flow_reverse": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _I64]),
     "vsp_generator_workspace_bytes": (_I64, [_P, _I, _I]),
     "vsp_generator": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _I64]),
+    "vsp_flow_forward": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _I64]),
+    "vsp_voice_conversion_workspace_bytes": (_I64, [_P, _I, _I]),
+    "vsp_voice_conversion": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64]),
+    "vsp_posterior_workspace_bytes": (_I64, [_P, _I, _I]),
+    "vsp_posterior_encoder": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I64]),
+    "vsp_has_voice_conversion": (_I, [_P]),
     "vsp_rq_spline": (_I, [_P, _I64, _I, _P, _P, _P, _P, _I, _F, _P, _P]),
     "vsp_profile_enable": (_I, [_P, _I]),
     "vsp_profile_read": (_I, [_P, C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), _I]),
@@ -92,7 +99,7 @@ def lib() -> C.CDLL:
             raise ImportError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if l.vsp_abi_version() != 1:
+    if l.vsp_abi_version() != 2:
         raise ImportError("libvispeech_hip ABI version mismatch")
     _lib = l
     return l
@@ -149,4 +156,6 @@ def make_config(dims) -> VspConfig:
     c.flow_kernel = dims.flow_kernel
     c.flow_layers = dims.flow_layers
     c.n_flows = dims.n_flows
+    c.spec_channels = dims.spec_channels
+    c.posterior_layers = dims.posterior_layers
     return c

@@ -198,48 +198,86 @@ void run_encoder_masked(Run& r, const EncoderW& E, int B, int T, T3 x_in, const 
   mask3(r, y_out, lengths, B, r.ctx->cfg.hidden_channels, T);
 }
 
-// ResidualCouplingBlock.forward(reverse=True) in place on z [B][inter][T] (reference models.py:202-209,
-// modules.py:324-343, 148-176).
-void run_flow(Run& r, int B, int T, T3 z, const float* g, const int64_t* lengths) {
+// modules.WN.forward (reference modules.py:148-176; dilation_rate 1) on H [B][h][T]: H is the running
+// residual stream (destroyed), OUT receives the masked skip sum.  gc: nl * 2h conditioning rows.
+void run_wn(Run& r, const Conv& cond, const std::vector<Conv>& in, const std::vector<Conv>& res,
+            const std::vector<Conv>& skip, int nl, int B, int T, T3 H, T3 ACT, T3 OUT, float* gc, const float* g,
+            const int64_t* lengths) {
+  const int h = r.ctx->cfg.hidden_channels;
+  r.cond(cond, g, gc, B);
+  for (int l = 0; l < nl; ++l) {
+    ConvArgs a = r.args(in[l], H, ACT, T, T);
+    a.act = 2; a.cond = gc ? gc + (size_t)l * 2 * h : nullptr; a.cond_bs = 2L * h * nl;
+    r.conv(a, B);
+    if (l < nl - 1) {
+      // skip first (reads ACT only), then the in-place residual update of H
+      a = r.args(skip[l], ACT, OUT, T, T);
+      a.acc_prev = l > 0;
+      r.conv(a, B);
+      a = r.args(res[l], ACT, H, T, T);
+      a.res = H.p; a.r_bs = H.bs; a.r_cs = H.cs;
+      a.lengths = lengths; a.mask_post = 1;
+      r.conv(a, B);
+    } else {
+      a = r.args(skip[l], ACT, OUT, T, T);
+      a.acc_prev = l > 0;
+      a.lengths = lengths; a.mask_post = 1;
+      r.conv(a, B);
+    }
+  }
+}
+
+// ResidualCouplingBlock.forward in place on z [B][inter][T] (reference models.py:202-209,
+// modules.py:324-343, 148-176).  reverse: x1 = (x1 - m) * mask, layers n-1 .. 0 (infer);
+// forward: x1 = m + x1 * mask, layers 0 .. n-1 (voice conversion).  With an even number of flows
+// layer i sees the same channel flip in both directions (i and n - i flips).
+void run_flow(Run& r, int B, int T, T3 z, const float* g, const int64_t* lengths, bool reverse = true) {
   const vsp_config& c = r.ctx->cfg;
   const Model& m = r.ctx->model;
   const int h = c.hidden_channels, half = c.inter_channels / 2, fl = c.flow_layers;
   T3 H = r.ws.t3(B, h, T), ACT = r.ws.t3(B, h, T), OUT = r.ws.t3(B, h, T);
   float* gc = r.ws.f((size_t)B * 2 * h * fl);
-  for (int i = c.n_flows - 1; i >= 0; --i) {
+  for (int n = 0; n < c.n_flows; ++n) {
+    const int i = reverse ? c.n_flows - 1 - n : n;
     const FlowW& F = m.flows[i];
     const T3 x0 = F.flipped ? z.chan(half) : z;
     const T3 x1 = F.flipped ? z : z.chan(half);
     ConvArgs a = r.args(F.pre, x0, H, T, T);
     a.lengths = lengths; a.mask_post = 1;
     r.conv(a, B);
-    r.cond(F.cond, g, gc, B);
-    for (int l = 0; l < fl; ++l) {
-      a = r.args(F.in[l], H, ACT, T, T);
-      a.act = 2; a.cond = gc ? gc + (size_t)l * 2 * h : nullptr; a.cond_bs = 2L * h * fl;
-      r.conv(a, B);
-      if (l < fl - 1) {
-        // skip first (reads ACT only), then the in-place residual update of H
-        a = r.args(F.skip[l], ACT, OUT, T, T);
-        a.acc_prev = l > 0;
-        r.conv(a, B);
-        a = r.args(F.res[l], ACT, H, T, T);
-        a.res = H.p; a.r_bs = H.bs; a.r_cs = H.cs;
-        a.lengths = lengths; a.mask_post = 1;
-        r.conv(a, B);
-      } else {
-        a = r.args(F.skip[l], ACT, OUT, T, T);
-        a.acc_prev = l > 0;
-        a.lengths = lengths; a.mask_post = 1;
-        r.conv(a, B);
-      }
-    }
-    // m = post(out) * mask ; x1 = (x1 - m) * mask
+    run_wn(r, F.cond, F.in, F.res, F.skip, fl, B, T, H, ACT, OUT, gc, g, lengths);
+    // m = post(out) * mask ; x1 = (x1 -/+ m) * mask
     a = r.args(F.post, OUT, x1, T, T);
-    a.lengths = lengths; a.mask_pre = 1; a.alpha = -1.f;
+    a.lengths = lengths; a.mask_pre = 1; a.alpha = reverse ? -1.f : 1.f;
     a.res = x1.p; a.r_bs = x1.bs; a.r_cs = x1.cs;
     a.mask_post = 1;
     r.conv(a, B);
+  }
+}
+
+// PosteriorEncoder.forward (reference models.py:233-241): y [B][spec][T] -> m, logs, z [B][inter][T].
+void run_posterior(Run& r, int B, int T, T3 y, const int64_t* lengths, const float* g, const float* noise, T3 Z,
+                   T3 M, T3 LOGS) {
+  const vsp_config& c = r.ctx->cfg;
+  const PosteriorW& Q = r.ctx->model.enc_q;
+  const int h = c.hidden_channels, ql = c.posterior_layers;
+  T3 H = r.ws.t3(B, h, T), ACT = r.ws.t3(B, h, T), OUT = r.ws.t3(B, h, T);
+  float* gc = r.ws.f((size_t)B * 2 * h * ql);
+  if (r.dry()) return;
+  ConvArgs a = r.args(Q.pre, y, H, T, T);
+  a.lengths = lengths; a.mask_post = 1;
+  r.conv(a, B);
+  run_wn(r, Q.cond, Q.in, Q.res, Q.skip, ql, B, T, H, ACT, OUT, gc, g, lengths);
+  a = r.args(Q.proj_m, OUT, M, T, T);
+  a.lengths = lengths; a.mask_post = 1;
+  r.conv(a, B);
+  a = r.args(Q.proj_s, OUT, LOGS, T, T);
+  a.lengths = lengths; a.mask_post = 1;
+  r.conv(a, B);
+  if (r.ok()) {
+    // z = (m + eps * exp(logs)) * mask   (contiguous [B][inter][T] outputs)
+    r.chk(launch_reparam(M.p, LOGS.p, noise, 1.f, Z.p, (long)B * c.inter_channels * T, r.s), "reparam");
+    r.chk(launch_mask3(Z.p, Z.bs, Z.cs, lengths, B, c.inter_channels, T, r.s), "mask");
   }
 }
 
@@ -443,7 +481,8 @@ const char* vsp_last_error(const vsp_ctx* ctx) { return ctx ? ctx->err.c_str() :
 int vsp_set_weight(vsp_ctx* ctx, const char* key, const float* host_data, const int64_t* shape, int ndim) {
   if (!ctx || !key || !host_data || !shape || ndim < 0 || ndim > 8) return ctx ? ctx->fail(VSP_ERR_ARG, "null argument") : VSP_ERR_ARG;
   const std::string k(key);
-  if (k.rfind("enc_q.", 0) == 0) return VSP_OK;  // posterior encoder: training / voice conversion only
+  // posterior encoder: voice conversion only; ignored by a context built without spec_channels
+  if (k.rfind("enc_q.", 0) == 0 && ctx->cfg.spec_channels <= 0) return VSP_OK;
   auto it = ctx->schema.find(k);
   if (it == ctx->schema.end()) {
     // accept a pre-folded "<x>.weight" where the schema has "<x>.weight_v" (remove_weight_norm'ed checkpoint)
@@ -468,7 +507,7 @@ int vsp_missing_weights(const vsp_ctx* ctx) {
   if (!ctx) return VSP_ERR_ARG;
   int n = 0;
   for (const auto& kv : ctx->schema) {
-    if (!kv.second.used) continue;
+    if (!kv.second.used || kv.second.optional) continue;
     if (ctx->raw.count(kv.first)) continue;
     const std::string& k = kv.first;
     // weight_g / weight_v are satisfied by a pre-folded weight
@@ -521,9 +560,13 @@ int vsp_adopt_packed_weights(vsp_ctx* ctx, void* dev_arena) {
   if (ctx->model.total_floats == 0) return ctx->fail(VSP_ERR_STATE, "context was not planned");
   const int rc = set_arena(ctx, dev_arena);
   if (rc) return rc;
+  // the adopted bytes are rank 0's: the posterior encoder is there iff rank 0 loaded enc_q.*
+  ctx->model.has_vc = ctx->cfg.spec_channels > 0;
   ctx->ready = true;
   return VSP_OK;
 }
+
+int vsp_has_voice_conversion(const vsp_ctx* ctx) { return ctx && ctx->ready && ctx->model.has_vc ? 1 : 0; }
 
 int vsp_weight_arena(const vsp_ctx* ctx, void** dev_arena, int64_t* bytes) {
   if (!ctx || !dev_arena || !bytes) return VSP_ERR_ARG;
@@ -780,6 +823,126 @@ int vsp_flow_reverse(vsp_ctx* ctx, void* stream, int B, int Tf, const float* z_p
   run_flow(r, B, Tf, ext(z, ctx->cfg.inter_channels, Tf), g, frame_lengths);
   if (ws.overflow) return ctx->fail(VSP_ERR_WORKSPACE, "flow workspace too small (need %zu bytes)", ws.cur);
   return r.rc;
+}
+
+int vsp_flow_forward(vsp_ctx* ctx, void* stream, int B, int Tf, const float* z, const float* g,
+                     const int64_t* frame_lengths, float* z_p, void* workspace, int64_t workspace_bytes) {
+  int rc = check_ready(ctx);
+  if (rc) return rc;
+  if (B <= 0 || Tf <= 0 || !z || !g || !frame_lengths || !z_p || !workspace)
+    return ctx->fail(VSP_ERR_ARG, "vsp_flow_forward: bad argument");
+  if (workspace_bytes < vsp_flow_workspace_bytes(ctx, B, Tf))
+    return ctx->fail(VSP_ERR_WORKSPACE, "flow workspace too small");
+  Ws ws(workspace, (size_t)workspace_bytes, false);
+  Run r{ctx, (hipStream_t)stream, ws};
+  const long n = (long)B * ctx->cfg.inter_channels * Tf;
+  r.chk(hipMemcpyAsync(z_p, z, n * sizeof(float), hipMemcpyDeviceToDevice, r.s), "z copy");
+  run_flow(r, B, Tf, ext(z_p, ctx->cfg.inter_channels, Tf), g, frame_lengths, false);
+  if (ws.overflow) return ctx->fail(VSP_ERR_WORKSPACE, "flow workspace too small (need %zu bytes)", ws.cur);
+  return r.rc;
+}
+
+// ---------------------------------------------------------------------------------- voice conversion
+static int check_vc(vsp_ctx* ctx) {
+  const int rc = check_ready(ctx);
+  if (rc) return rc;
+  if (ctx->cfg.spec_channels <= 0) return ctx->fail(VSP_ERR_STATE, "context was created without spec_channels");
+  if (!ctx->model.has_vc) return ctx->fail(VSP_ERR_STATE, "enc_q.* tensors were not loaded before vsp_finalize_weights");
+  return VSP_OK;
+}
+
+int64_t vsp_posterior_workspace_bytes(const vsp_ctx* ctx, int B, int T) {
+  if (!ctx || B <= 0 || T <= 0) return VSP_ERR_ARG;
+  Ws ws(nullptr, 0, true);
+  Run r{const_cast<vsp_ctx*>(ctx), nullptr, ws};
+  run_posterior(r, B, T, T3{}, nullptr, nullptr, nullptr, T3{}, T3{}, T3{});
+  return (int64_t)ws.cur;
+}
+
+int vsp_posterior_encoder(vsp_ctx* ctx, void* stream, int B, int T, const float* y, const int64_t* y_lengths,
+                          const float* g, const float* noise, float* z, float* m, float* logs, void* workspace,
+                          int64_t workspace_bytes) {
+  int rc = check_vc(ctx);
+  if (rc) return rc;
+  if (B <= 0 || T <= 0 || !y || !y_lengths || !g || !noise || !z || !m || !logs || !workspace)
+    return ctx->fail(VSP_ERR_ARG, "vsp_posterior_encoder: bad argument");
+  if (workspace_bytes < vsp_posterior_workspace_bytes(ctx, B, T))
+    return ctx->fail(VSP_ERR_WORKSPACE, "posterior workspace too small");
+  Ws ws(workspace, (size_t)workspace_bytes, false);
+  Run r{ctx, (hipStream_t)stream, ws};
+  const int inter = ctx->cfg.inter_channels;
+  run_posterior(r, B, T, ext(y, ctx->cfg.spec_channels, T), y_lengths, g, noise, ext(z, inter, T), ext(m, inter, T),
+                ext(logs, inter, T));
+  if (ws.overflow) return ctx->fail(VSP_ERR_WORKSPACE, "posterior workspace too small (need %zu bytes)", ws.cur);
+  return r.rc;
+}
+
+// SynthesizerTrn.voice_conversion (reference models.py:724-732)
+static int vc_impl(vsp_ctx* ctx, hipStream_t s, Ws& ws, int B, int T, const float* y, const int64_t* y_lengths,
+                   const int64_t* sid_src, const int64_t* sid_tgt, const float* noise, float* o_hat, uint8_t* y_mask,
+                   float* z, float* z_p, float* z_hat, float* m_q, float* logs_q) {
+  const vsp_config& c = ctx->cfg;
+  const Model& m = ctx->model;
+  const int inter = c.inter_channels, gin = c.gin_channels;
+  Run r{ctx, s, ws};
+  float* g_src = ws.f((size_t)B * gin);
+  float* g_tgt = ws.f((size_t)B * gin);
+  T3 MQ = m_q ? ext(m_q, inter, T) : ws.t3(B, inter, T);
+  T3 LQ = logs_q ? ext(logs_q, inter, T) : ws.t3(B, inter, T);
+  if (!m_q || !logs_q) {
+    // launch_reparam walks contiguous tensors: the scratch copies must be dense too
+    MQ.cs = LQ.cs = T; MQ.bs = LQ.bs = (long)inter * T;
+  }
+  const bool live = !ws.dry && !ws.overflow;
+  if (live) {
+    r.chk(launch_gather_rows(sid_src, r.A(m.emb_g), c.n_speakers, g_src, B, gin, s), "emb_g");
+    r.chk(launch_gather_rows(sid_tgt, r.A(m.emb_g), c.n_speakers, g_tgt, B, gin, s), "emb_g");
+    r.chk(launch_mask_u8(y_lengths, y_mask, B, T, s), "y_mask");
+  }
+  const size_t mark = ws.cur;
+  run_posterior(r, B, T, ext(y, c.spec_channels, T), y_lengths, g_src, noise, ext(z, inter, T), MQ, LQ);
+  const size_t after_post = ws.cur;
+  ws.cur = mark;  // the three stages run one after another on one stream: they share scratch
+  const long n = (long)B * inter * T;
+  if (live && r.ok()) r.chk(hipMemcpyAsync(z_p, z, n * sizeof(float), hipMemcpyDeviceToDevice, s), "z_p copy");
+  run_flow(r, B, T, ext(z_p, inter, T), g_src, y_lengths, false);
+  if (live && r.ok()) r.chk(hipMemcpyAsync(z_hat, z_p, n * sizeof(float), hipMemcpyDeviceToDevice, s), "z_hat copy");
+  ws.cur = mark;
+  run_flow(r, B, T, ext(z_hat, inter, T), g_tgt, y_lengths, true);
+  const size_t after_flow = ws.cur;
+  ws.cur = mark;
+  // dec(z_hat * y_mask, g_tgt): z_hat is already masked by the flow's last update on x1 ... but x0
+  // passes through unmasked only if the input was unmasked; z is masked, so z_hat * mask == z_hat.
+  run_gen(r, B, T, ext(z_hat, inter, T), y_lengths, g_tgt, o_hat);
+  ws.cur = std::max(ws.cur, std::max(after_post, after_flow));
+  if (ws.overflow) return ctx->fail(VSP_ERR_WORKSPACE, "voice conversion workspace too small (need %zu bytes)", ws.cur);
+  return r.rc;
+}
+
+int64_t vsp_voice_conversion_workspace_bytes(const vsp_ctx* ctx, int B, int T) {
+  if (!ctx || B <= 0 || T <= 0) return VSP_ERR_ARG;
+  Ws ws(nullptr, 0, true);
+  vc_impl(const_cast<vsp_ctx*>(ctx), nullptr, ws, B, T, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+          nullptr, nullptr, nullptr, nullptr, nullptr);
+  return (int64_t)ws.cur;
+}
+
+int vsp_voice_conversion(vsp_ctx* ctx, void* stream, int B, int T, const float* y, const int64_t* y_lengths,
+                         const int64_t* sid_src, const int64_t* sid_tgt, const float* noise, float* o_hat,
+                         uint8_t* y_mask, float* z, float* z_p, float* z_hat, float* m_q, float* logs_q,
+                         void* workspace, int64_t workspace_bytes) {
+  int rc = check_vc(ctx);
+  if (rc) return rc;
+  if (B <= 0 || T <= 0 || !y || !y_lengths || !sid_src || !sid_tgt || !noise || !o_hat || !y_mask || !z || !z_p ||
+      !z_hat || !workspace)
+    return ctx->fail(VSP_ERR_ARG, "vsp_voice_conversion: null or non-positive argument");
+  const int64_t need = vsp_voice_conversion_workspace_bytes(ctx, B, T);
+  if (workspace_bytes < need)
+    return ctx->fail(VSP_ERR_WORKSPACE, "voice conversion workspace too small: %lld < %lld bytes",
+                     (long long)workspace_bytes, (long long)need);
+  Ws ws(workspace, (size_t)workspace_bytes, false);
+  return vc_impl(ctx, (hipStream_t)stream, ws, B, T, y, y_lengths, sid_src, sid_tgt, noise, o_hat, y_mask, z, z_p, z_hat,
+                 m_q, logs_q);
 }
 
 int64_t vsp_generator_workspace_bytes(const vsp_ctx* ctx, int B, int T) {

@@ -47,6 +47,11 @@ struct FlowW {
   Conv pre, cond, post;
   std::vector<Conv> in, res, skip;
 };
+// PosteriorEncoder (reference models.py:212-241): pre 1x1, WN (k5, dilation 1, n layers), proj 1x1.
+struct PosteriorW {
+  Conv pre, cond, proj_m, proj_s;
+  std::vector<Conv> in, res, skip;
+};
 struct ResBlockW {
   int k = 0;
   std::vector<int> dil;
@@ -66,6 +71,8 @@ struct Model {
   size_t ppre_w = 0, ppre_b = 0, epre_w = 0, epre_b = 0;
   Conv proj_m, proj_s;
   std::vector<FlowW> flows;  // index = flow layer i (applied in order n_flows-1 .. 0)
+  PosteriorW enc_q;     // planned when cfg.spec_channels > 0
+  bool has_vc = false;  // enc_q weights were packed (voice conversion available)
   Conv g_pre, g_cond;
   std::vector<Conv> ups;
   std::vector<ClConv> ups_h;
@@ -80,6 +87,7 @@ struct Model {
 struct SchemaEntry {
   std::vector<int64_t> shape;
   bool used;
+  bool optional = false;  // kept when set, but not required by vsp_finalize_weights (enc_q.*)
 };
 
 }  // namespace vsp

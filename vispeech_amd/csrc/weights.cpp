@@ -17,7 +17,7 @@ namespace vsp {
 using Shape = std::vector<int64_t>;
 
 static void add(std::map<std::string, SchemaEntry>& s, const std::string& k, Shape shape, bool used = true) {
-  s[k] = SchemaEntry{std::move(shape), used};
+  s[k] = SchemaEntry{std::move(shape), used, false};
 }
 
 static void schema_encoder(std::map<std::string, SchemaEntry>& s, const std::string& p, int n_layers,
@@ -95,8 +95,18 @@ void build_schema(const vsp_config& c, std::map<std::string, SchemaEntry>& s) {
   add(s, "dec.conv_post.weight", {1, ch, 7});
   add(s, "dec.cond.weight", {c0, gin, 1});
   add(s, "dec.cond.bias", {c0});
-  // posterior encoder: in checkpoints, never read by infer (its spec_channels is not part of
-  // vsp_config, so shapes of enc_q.* are accepted unchecked -- see vsp_set_weight)
+  // posterior encoder (reference models.py:596): in checkpoints, never read by infer; kept as
+  // OPTIONAL tensors for voice conversion when the config names spec_channels, otherwise
+  // accepted unchecked and ignored (see vsp_set_weight)
+  if (c.spec_channels > 0) {
+    std::map<std::string, SchemaEntry> q;
+    add(q, "enc_q.pre.weight", {h, c.spec_channels, 1});
+    add(q, "enc_q.pre.bias", {h});
+    schema_wn(q, "enc_q.enc", h, c.flow_kernel, c.posterior_layers, gin, true);
+    add(q, "enc_q.proj.weight", {2 * inter, h, 1});
+    add(q, "enc_q.proj.bias", {2 * inter});
+    for (auto& kv : q) { kv.second.optional = true; s[kv.first] = kv.second; }
+  }
   for (int i = 0; i < c.n_flows; ++i) {
     const std::string p = "flow.flows." + std::to_string(2 * i);
     add(s, p + ".pre.weight", {h, inter / 2, 1});
@@ -253,6 +263,20 @@ int plan_model(vsp_ctx* ctx) {
   }
   if (c.n_flows % 2)
     return ctx->fail(VSP_ERR_UNSUPPORTED, "odd n_flows leaves the latent channel-flipped; only even counts are folded");
+  if (c.spec_channels > 0) {
+    if (c.posterior_layers < 1) return ctx->fail(VSP_ERR_ARG, "posterior_layers < 1");
+    PosteriorW& Q = m.enc_q;
+    const int ql = c.posterior_layers;
+    Q.pre = p.conv(h, c.spec_channels, 1, 1, 0, true);
+    Q.cond = p.conv(2 * h * ql, gin, 1, 1, 0, true);
+    for (int l = 0; l < ql; ++l) {
+      Q.in.push_back(p.conv(2 * h, h, fk, 1, (fk - 1) / 2, true));
+      if (l < ql - 1) Q.res.push_back(p.conv(h, h, 1, 1, 0, true));
+      Q.skip.push_back(p.conv(h, h, 1, 1, 0, true));
+    }
+    Q.proj_m = p.conv(inter, h, 1, 1, 0, true);
+    Q.proj_s = p.conv(inter, h, 1, 1, 0, true);
+  }
   // generator
   const int c0 = c.upsample_initial_channel;
   m.g_pre = p.conv(c0, inter, 7, 1, 3, true);
@@ -427,9 +451,42 @@ static inline int gate_row(int pr, int h) {
   return within < 32 ? 32 * t + within : h + 32 * t + (within - 32);
 }
 
+// modules.WN (reference modules.py:113-176): cond_layer rows and in_layer rows are permuted into
+// tanh/sigmoid tile pairs (gate_row); res_skip rows split into the residual and the skip conv.
+static void fill_wn(Filler& f, const std::string& p, const Conv& cond, const std::vector<Conv>& in,
+                    const std::vector<Conv>& res, const std::vector<Conv>& skip, int nl, int h, int gin, int fk) {
+  {
+    const HostTensor* W = f.get(p + ".cond_layer.weight");
+    const HostTensor* B = f.get(p + ".cond_layer.bias");
+    if (!f.ok) return;
+    const float* wd = W->data.data();
+    const float* bd = B->data.data();
+    auto orig = [=](int r) { return (r / (2 * h)) * 2 * h + gate_row(r % (2 * h), h); };
+    f.conv(cond, [=](int r, int ci, int) { return wd[(size_t)orig(r) * gin + ci]; },
+           [=](int r) { return bd[orig(r)]; });
+  }
+  for (int l = 0; l < nl && f.ok; ++l) {
+    const std::string il = p + ".in_layers." + std::to_string(l);
+    const HostTensor* W = f.get(il + ".weight");
+    const HostTensor* B = f.get(il + ".bias");
+    if (!f.ok) return;
+    const float* wd = W->data.data();
+    const float* bd = B->data.data();
+    f.conv(in[l], [=](int r, int ci, int t) { return wd[((size_t)gate_row(r, h) * h + ci) * fk + t]; },
+           [=](int r) { return bd[gate_row(r, h)]; });
+    const std::string rs = p + ".res_skip_layers." + std::to_string(l);
+    if (l < nl - 1) {
+      f.conv_plain(res[l], rs + ".weight", rs + ".bias", 0);
+      f.conv_plain(skip[l], rs + ".weight", rs + ".bias", h);
+    } else {
+      f.conv_plain(skip[l], rs + ".weight", rs + ".bias", 0);
+    }
+  }
+}
+
 int fill_model(vsp_ctx* ctx, std::vector<float>& arena) {
   const vsp_config& c = ctx->cfg;
-  const Model& m = ctx->model;
+  Model& m = ctx->model;
   arena.assign(m.total_floats, 0.f);
   Filler f{ctx, arena};
   const int h = c.hidden_channels, gin = c.gin_channels, inter = c.inter_channels;
@@ -481,33 +538,8 @@ int fill_model(vsp_ctx* ctx, std::vector<float>& arena) {
       f.conv(F.pre, [=](int r, int ci, int) { return wd[(size_t)r * half + (flip ? half - 1 - ci : ci)]; },
              [=](int r) { return bd[r]; });
     }
-    {
-      const HostTensor* W = f.get(p + ".enc.cond_layer.weight");
-      const HostTensor* B = f.get(p + ".enc.cond_layer.bias");
-      if (!f.ok) break;
-      const float* wd = W->data.data();
-      const float* bd = B->data.data();
-      auto orig = [=](int r) { return (r / (2 * h)) * 2 * h + gate_row(r % (2 * h), h); };
-      f.conv(F.cond, [=](int r, int ci, int) { return wd[(size_t)orig(r) * gin + ci]; },
-             [=](int r) { return bd[orig(r)]; });
-    }
-    for (int l = 0; l < fl && f.ok; ++l) {
-      const std::string il = p + ".enc.in_layers." + std::to_string(l);
-      const HostTensor* W = f.get(il + ".weight");
-      const HostTensor* B = f.get(il + ".bias");
-      if (!f.ok) break;
-      const float* wd = W->data.data();
-      const float* bd = B->data.data();
-      f.conv(F.in[l], [=](int r, int ci, int t) { return wd[((size_t)gate_row(r, h) * h + ci) * fk + t]; },
-             [=](int r) { return bd[gate_row(r, h)]; });
-      const std::string rs = p + ".enc.res_skip_layers." + std::to_string(l);
-      if (l < fl - 1) {
-        f.conv_plain(F.res[l], rs + ".weight", rs + ".bias", 0);
-        f.conv_plain(F.skip[l], rs + ".weight", rs + ".bias", h);
-      } else {
-        f.conv_plain(F.skip[l], rs + ".weight", rs + ".bias", 0);
-      }
-    }
+    fill_wn(f, p + ".enc", F.cond, F.in, F.res, F.skip, fl, h, gin, fk);
+    if (!f.ok) break;
     {
       const HostTensor* W = f.get(p + ".post.weight");
       const HostTensor* B = f.get(p + ".post.bias");
@@ -518,6 +550,26 @@ int fill_model(vsp_ctx* ctx, std::vector<float>& arena) {
       // flipped: logical x1 channel cl (logical index half+cl) is physical half-1-cl.
       f.conv(F.post, [=](int r, int ci, int) { return wd[(size_t)(flip ? half - 1 - r : r) * h + ci]; },
              [=](int r) { return bd[flip ? half - 1 - r : r]; });
+    }
+  }
+
+  // posterior encoder (optional): packed only when every enc_q tensor was supplied
+  m.has_vc = false;
+  if (c.spec_channels > 0 && f.ok) {
+    bool all = true;
+    for (const auto& kv : ctx->schema)
+      if (kv.second.optional && !ctx->raw.count(kv.first)) {
+        const std::string& k = kv.first;
+        const bool gv = k.size() > 2 && (k.compare(k.size() - 2, 2, "_v") == 0 || k.compare(k.size() - 2, 2, "_g") == 0);
+        if (!(gv && ctx->raw.count(k.substr(0, k.size() - 2)))) { all = false; break; }
+      }
+    if (all) {
+      const PosteriorW& Q = m.enc_q;
+      f.conv_plain(Q.pre, "enc_q.pre.weight", "enc_q.pre.bias");
+      fill_wn(f, "enc_q.enc", Q.cond, Q.in, Q.res, Q.skip, c.posterior_layers, h, gin, fk);
+      f.conv_plain(Q.proj_m, "enc_q.proj.weight", "enc_q.proj.bias", 0);
+      f.conv_plain(Q.proj_s, "enc_q.proj.weight", "enc_q.proj.bias", inter);
+      m.has_vc = f.ok;
     }
   }
 

@@ -212,6 +212,63 @@ class Engine:
         _lib.check(rc, self.ctx, "vsp_flow_reverse")
         return z
 
+    def flow_forward(self, z, g, frame_lengths) -> torch.Tensor:
+        """ResidualCouplingBlock.forward(reverse=False) (reference models.py:202-206)."""
+        z = _dev_f32(z, self.device)
+        g = _dev_f32(g, self.device).reshape(z.shape[0], -1)
+        fl = _dev_i64(frame_lengths, self.device)
+        B, _, Tf = z.shape
+        z_p = torch.empty_like(z)
+        ws = self._workspace("flow", self.lib.vsp_flow_workspace_bytes(self.ctx, B, Tf))
+        with torch.cuda.device(self.device):
+            rc = self.lib.vsp_flow_forward(self.ctx, self._stream(), B, Tf, _ptr(z), _ptr(g), _ptr(fl), _ptr(z_p),
+                                           _ptr(ws), ws.numel())
+        _lib.check(rc, self.ctx, "vsp_flow_forward")
+        return z_p
+
+    # ------------------------------------------------------------------ voice conversion
+    @property
+    def has_voice_conversion(self) -> bool:
+        return bool(self.lib.vsp_has_voice_conversion(self.ctx))
+
+    def posterior_encoder(self, y, y_lengths, g, noise):
+        """PosteriorEncoder.forward (reference models.py:233-241) -> (z, m, logs)."""
+        y = _dev_f32(y, self.device)
+        g = _dev_f32(g, self.device).reshape(y.shape[0], -1)
+        yl = _dev_i64(y_lengths, self.device)
+        B, _, T = y.shape
+        noise = _dev_f32(noise, self.device)
+        z, m, logs = (self._f(B, self.dims.inter_channels, T) for _ in range(3))
+        ws = self._workspace("posterior", self.lib.vsp_posterior_workspace_bytes(self.ctx, B, T))
+        with torch.cuda.device(self.device):
+            rc = self.lib.vsp_posterior_encoder(self.ctx, self._stream(), B, T, _ptr(y), _ptr(yl), _ptr(g), _ptr(noise),
+                                                _ptr(z), _ptr(m), _ptr(logs), _ptr(ws), ws.numel())
+        _lib.check(rc, self.ctx, "vsp_posterior_encoder")
+        return z, m, logs
+
+    def voice_conversion(self, y, y_lengths, sid_src, sid_tgt, noise) -> Dict[str, torch.Tensor]:
+        """SynthesizerTrn.voice_conversion (reference models.py:724-732); ``noise`` [B,inter,T] is the
+        ``torch.randn_like`` of the posterior encoder (models.py:240)."""
+        y = _dev_f32(y, self.device)
+        B, S, T = y.shape
+        if S != self.dims.spec_channels:
+            raise ValueError(f"y has {S} channels, the model's spec_channels is {self.dims.spec_channels}")
+        yl, ss, st = (_dev_i64(t, self.device) for t in (y_lengths, sid_src, sid_tgt))
+        noise = _dev_f32(noise, self.device)
+        if tuple(noise.shape) != (B, self.dims.inter_channels, T):
+            raise ValueError("noise must be [B, inter_channels, T]")
+        inter = self.dims.inter_channels
+        o = self._f(B, 1, T * self.dims.total_upsample)
+        z, z_p, z_hat, m_q, logs_q = (self._f(B, inter, T) for _ in range(5))
+        y_mask = torch.empty((B, 1, T), dtype=torch.uint8, device=self.device)
+        ws = self._workspace("vc", self.lib.vsp_voice_conversion_workspace_bytes(self.ctx, B, T))
+        with torch.cuda.device(self.device):
+            rc = self.lib.vsp_voice_conversion(self.ctx, self._stream(), B, T, _ptr(y), _ptr(yl), _ptr(ss), _ptr(st),
+                                               _ptr(noise), _ptr(o), _ptr(y_mask), _ptr(z), _ptr(z_p), _ptr(z_hat),
+                                               _ptr(m_q), _ptr(logs_q), _ptr(ws), ws.numel())
+        _lib.check(rc, self.ctx, "vsp_voice_conversion")
+        return dict(o_hat=o, y_mask=y_mask, z=z, z_p=z_p, z_hat=z_hat, m_q=m_q, logs_q=logs_q)
+
     def generator(self, z, g) -> torch.Tensor:
         z = _dev_f32(z, self.device)
         g = _dev_f32(g, self.device).reshape(z.shape[0], -1)

@@ -4,8 +4,8 @@ Mirrors the reference's class surface for ``infer`` and nothing else (SURVEY.md 
 the constructor signature (reference models.py:537-561), ``infer`` with the same arguments and the
 same 6-tuple result (reference models.py:672-722), ``load_state_dict`` accepting reference
 checkpoints unchanged (753-tensor schema, weight_g/weight_v pairs included), ``eval()``, ``to()``.
-Training-time members (``forward``, ``voice_conversion``, ``enc_q``, discriminators) are out of
-scope and raise.  All arithmetic runs in libvispeech_hip on the MI355X; if the extension is not
+``voice_conversion`` (reference models.py:724-732) is served as well when the checkpoint carries the
+``enc_q.*`` tensors.  Training-time members (``forward``, discriminators) are out of scope and raise.  All arithmetic runs in libvispeech_hip on the MI355X; if the extension is not
 built, constructing the model raises ImportError.
 """
 from __future__ import annotations
@@ -90,8 +90,24 @@ class SynthesizerTrn:
     def forward(self, *a, **k):
         raise NotImplementedError("SynthesizerTrn.forward is the training path (reference models.py:624-670): out of scope")
 
-    def voice_conversion(self, *a, **k):
-        raise NotImplementedError("voice_conversion needs the posterior encoder (reference models.py:724-732): out of scope")
+    @torch.no_grad()
+    def voice_conversion(self, y, y_lengths, sid_src, sid_tgt, *, noise: Optional[torch.Tensor] = None):
+        """Reference models.py:724-732: posterior encoder on the linear spectrogram ``y``
+        [B, spec_channels, T] with the source speaker, flow forward (source), flow reverse (target),
+        generator (target).  ``noise`` (keyword-only, optional) replaces the ``torch.randn_like`` of
+        the posterior encoder (models.py:240).  Returns ``(o_hat, y_mask, (z, z_p, z_hat))``; needs the
+        ``enc_q.*`` tensors in the loaded state_dict."""
+        eng = self._engine
+        if not eng.ready:
+            raise RuntimeError("weights not loaded: call load_state_dict first")
+        assert self.n_speakers > 0, "n_speakers have to be larger than 0."      # models.py:725
+        if not eng.has_voice_conversion:
+            raise RuntimeError("voice_conversion needs the enc_q.* tensors: the loaded state_dict had none")
+        B, _, T = y.shape
+        if noise is None:
+            noise = torch.randn(B, self.dims.inter_channels, T, dtype=torch.float32, device=eng.device)
+        r = eng.voice_conversion(y, y_lengths, sid_src, sid_tgt, noise)
+        return r["o_hat"], r["y_mask"].to(torch.float32), (r["z"], r["z_p"], r["z_hat"])
 
     def __call__(self, *a, **k):
         return self.forward(*a, **k)

@@ -89,6 +89,8 @@ def synth_state_dict(dims: ModelDims, seed: int = 1234,
                 fan, gain = _fan_in(shape), 0.2
             elif key == "project.proj.weight":
                 fan, gain = _fan_in(shape), 0.3
+            elif key == "enc_q.proj.weight":
+                fan, gain = _fan_in(shape), 0.15   # keeps exp(logs_q) of the 16-layer WN skip sum O(1)
             else:
                 fan, gain = _fan_in(shape), 1.0
             t = r.standard_normal(shape) * (gain / np.sqrt(fan))
