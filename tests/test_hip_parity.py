@@ -386,3 +386,22 @@ def test_reduced_precision_mode_is_opt_in_and_gated(dims, weights, golden_dir, m
     print(f"f16 generator: SNR {snr:.1f} dB, max rel err {e:.2e}")
     assert snr >= 30.0
     assert e > 1e-5          # i.e. really the reduced-precision path
+
+
+def test_fused_resblock_pairs_are_bit_identical_to_two_launches(net, dims, weights, monkeypatch):
+    """The 32/64-channel ResBlock conv pairs run as ONE launch (respair_f16s.hip: the intermediate stays in
+    LDS) by default; VSP_FUSE_PAIRS=0 runs them as two cl_conv_f16s launches.  Same split products, same
+    accumulation order => identical bits, for tiles that start/end anywhere in the utterance."""
+    monkeypatch.setenv("VSP_FUSE_PAIRS", "0")
+    from vispeech_amd import config as vcfg
+    from vispeech_amd.models import SynthesizerTrn
+    args, kwargs = vcfg.synthesizer_args(vcfg.default_hparams())
+    two = SynthesizerTrn(*args, **kwargs).eval()
+    two.load_state_dict(weights, strict=True)
+    r = np.random.Generator(np.random.PCG64(5))
+    for B, T in ((3, 37), (2, 1), (1, 130), (5, 64)):
+        z = torch.from_numpy(r.standard_normal((B, dims.inter_channels, T)).astype(np.float32))
+        g = torch.from_numpy(r.standard_normal((B, dims.gin_channels)).astype(np.float32))
+        a = net._engine.generator(z, g)
+        b = two._engine.generator(z, g)
+        assert torch.equal(a, b), (B, T, float((a - b).abs().max()))

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Per-launch figures of the generator (fused ResBlock pairs on the 64/32-channel stages) from a
+rocprofv3 --kernel-trace CSV.  usage: trace_fused.py <kernel_trace.csv> [B] [T_frames]"""
+import csv
+import sys
+
+path = sys.argv[1]
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+T = int(sys.argv[3]) if len(sys.argv) > 3 else 489
+rows = list(csv.DictReader(open(path)))
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+idx = [i for i, r in enumerate(rows) if 'conv_post' in r['Kernel_Name']]
+seg = rows[idx[-2] + 1: idx[-1] + 1]
+gen = [r for r in seg if ('cl_conv' in r['Kernel_Name'] or 'respair' in r['Kernel_Name'])]
+c0 = 512
+rates = [8, 8, 4, 2]; uk = [16, 16, 4, 4]; ks = [3, 7, 11]
+specs = []
+t = T
+for i in range(4):
+    cin = c0 >> i; cout = c0 >> (i + 1); s = rates[i]
+    specs.append((f'ups{i}', 'conv', cout, cin, uk[i], t, t * s, 0))
+    t *= s
+    for k in ks:
+        for d in (1, 3, 5):
+            if cout <= 64:
+                specs.append((f's{i}k{k}d{d}', 'pair', cout, cout, k, t, t, 1))
+            else:
+                specs.append((f's{i}k{k}d{d}a', 'conv', cout, cout, k, t, t, 0))
+                specs.append((f's{i}k{k}d1b', 'conv', cout, cout, k, t, t, 1))
+if len(gen) != len(specs):
+    print(f"# note: {len(gen)} launches vs {len(specs)} expected")
+tot = 0
+stage = {}
+for (name, kind, co, ci, K, N, Nout, res), r in zip(specs, gen):
+    dur = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6
+    if kind == 'pair':
+        fl = 2 * 2.0 * co * ci * K * N * B
+        byt = 4.0 * B * N * co * 5           # layer-boundary model of the two convs
+        real = 4.0 * B * N * co * 3          # x in, residual x, y out
+    else:
+        fl = 2.0 * co * ci * K * N * B
+        byt = 4.0 * B * (N * ci + Nout * co * (1 + res))
+        real = byt
+    tot += dur
+    key = name[:2] if name[0] == 's' else name
+    stage[key] = stage.get(key, 0) + dur
+    print(f"{name:10s} {kind:4s} C={co:4d} K={K:2d} rows={N:7d} {dur:7.3f} ms  alg {fl/dur/1e9:6.1f} TF/s  mfma-issue "
+          f"{3*fl/dur/1e9/2500*100:5.1f}%  alg {byt/dur/1e6:7.1f} GB/s  moved>= {real/dur/1e6:7.1f} GB/s  vgpr={r['VGPR_Count']}")
+print('per stage ms:', {k: round(v, 2) for k, v in stage.items()})
+print(f'total {tot:.2f} ms')

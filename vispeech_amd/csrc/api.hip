@@ -134,6 +134,42 @@ struct Run {
       ctx->prof_bytes += 4.0 * B * (in_el + out_el * (1.0 + (res ? 1.0 : 0.0) + (acc_prev ? 1.0 : 0.0)));
     }
   }
+  // fused ResBlock1 pair (respair_f16s.hip): out = x + conv2(lrelu(conv1(lrelu(x)))) [+ out] [/ div]
+  void clpair(const ClConv& L1, const ClConv& L2, const float* x, float* out, long bs, int T, bool acc_prev, float div,
+              int B) {
+    if (dry() || !ok()) return;
+    ClPairArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.x = x; a.x_bs = bs; a.out = out; a.o_bs = bs;
+    a.w1h = reinterpret_cast<const uint16_t*>(A(L1.wh)); a.w1l = reinterpret_cast<const uint16_t*>(A(L1.wl));
+    a.w2h = reinterpret_cast<const uint16_t*>(A(L2.wh)); a.w2l = reinterpret_cast<const uint16_t*>(A(L2.wl));
+    a.b1 = A((size_t)L1.b); a.b2 = A((size_t)L2.b);
+    a.C = L1.Cout; a.K = L1.K; a.dil = L1.dil; a.T = T;
+    a.slope = 0.1f;                                    // modules.LRELU_SLOPE (reference modules.py:17)
+    a.acc_prev = acc_prev ? 1 : 0; a.div = div;
+    a.terms = ctx->gen_mode == 2 ? 1 : 3;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->prof_on) {
+      while (ctx->ev_pool.size() < ctx->ev_used + 2) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) { rc = ctx->fail(VSP_ERR_HIP, "hipEventCreate"); return; }
+        ctx->ev_pool.push_back(e);
+      }
+      e0 = ctx->ev_pool[ctx->ev_used++];
+      e1 = ctx->ev_pool[ctx->ev_used++];
+      (void)hipEventRecord(e0, s);
+    }
+    chk(launch_cl_pair(a, B, s), "cl_respair_f16s");
+    if (e1) {
+      (void)hipEventRecord(e1, s);
+      ctx->prof_launches += 1;
+      ctx->prof_flops += 2.0 * 2.0 * L1.Cout * L1.Cin * L1.K * (double)T * B;
+      // algorithmic (layer-boundary) bytes of the two convs this launch replaces: conv1 in + out,
+      // conv2 in + out + residual (+ accumulate) -- SURVEY.md section 8d's traffic model
+      const double el = (double)T * L1.Cout;
+      ctx->prof_bytes += 4.0 * B * el * (5.0 + (acc_prev ? 1.0 : 0.0));
+    }
+  }
   // cond(g): 1x1 conv on g [B][gin] (T = 1) -> out [B][M]
   void cond(const Conv& L, const float* g, float* out, int B) {
     const int gin = L.Cin;
@@ -410,12 +446,23 @@ void run_generator_cl(Run& r, int B, int T, T3 z, const int64_t* in_lengths, con
       for (int j = 0; j < nk; ++j) {
         const ResBlockW& rb = m.rbs[i * nk + j];
         const int nd = (int)rb.dil.size();
+        bool fuse = r.ctx->fuse_pairs;
+        for (int d = 0; d < nd; ++d) fuse = fuse && cl_pair_supported(ch, rb.k, rb.dil[d]);
         for (int d = 0; d < nd; ++d) {
-          const float* yin = d == 0 ? xu : ya;
-          r.clconv(rb.h1[d], yin, bs, t1, bs, nullptr, 0, (int)Tout, (int)Tout, (int)Tout, 0.1f, false, 1.f, nb);
           const bool last = d == nd - 1;
-          r.clconv(rb.h2[d], t1, bs, last ? xs : ya, bs, yin, bs, (int)Tout, (int)Tout, (int)Tout, 0.1f,
-                   last && j > 0, (last && j == nk - 1) ? (float)nk : 1.f, nb);
+          const float div = (last && j == nk - 1) ? (float)nk : 1.f;
+          if (fuse) {
+            // one launch per pair; the running y ping-pongs between ya and t1 (a block reads halo rows
+            // that a neighbour writes, so a pair cannot run in place)
+            const float* yin = d == 0 ? xu : ((d & 1) ? ya : t1);
+            float* yout = last ? xs : ((d & 1) ? t1 : ya);
+            r.clpair(rb.h1[d], rb.h2[d], yin, yout, bs, (int)Tout, last && j > 0, div, nb);
+          } else {
+            const float* yin = d == 0 ? xu : ya;
+            r.clconv(rb.h1[d], yin, bs, t1, bs, nullptr, 0, (int)Tout, (int)Tout, (int)Tout, 0.1f, false, 1.f, nb);
+            r.clconv(rb.h2[d], t1, bs, last ? xs : ya, bs, yin, bs, (int)Tout, (int)Tout, (int)Tout, 0.1f,
+                     last && j > 0, div, nb);
+          }
         }
       }
     }
@@ -464,6 +511,7 @@ int vsp_create(const vsp_config* cfg, int device, vsp_ctx** out) {
     if (!strcmp(e, "f16") && ctx->gen_mode == 1) ctx->gen_mode = 2;   // opt-in reduced precision
   }
   if (const char* e = getenv("VSP_CHUNK_MB")) ctx->chunk_mb = atof(e);
+  if (const char* e = getenv("VSP_FUSE_PAIRS")) ctx->fuse_pairs = atoi(e) != 0;
   *out = ctx;  // returned even on failure so that vsp_last_error can be read; caller destroys it
   return rc;
 }

@@ -59,6 +59,22 @@ struct ClConvArgs {
   int terms;                                // 3 = fp32-accurate split product (default), 1 = plain f16 operands
 };
 hipError_t launch_cl_conv(const ClConvArgs& a, int B, hipStream_t s);
+
+// Fused ResBlock1 conv pair on channels-last activations (respair_f16s.hip):
+//   out = x + conv2(lrelu(conv1(lrelu(x), dil) + b1), 1) + b2  [+ out] [/ div];  x != out.
+struct ClPairArgs {
+  const float* x; long x_bs;                // [B][T][C], batch stride in elements
+  const uint16_t *w1h, *w1l; const float* b1;   // conv1 (dilation dil): packed f16 hi / lo fragments, bias
+  const uint16_t *w2h, *w2l; const float* b2;   // conv2 (dilation 1)
+  float* out; long o_bs;
+  int C, K, dil, T;
+  float slope;                              // leaky-relu slope applied to both convs' inputs
+  int acc_prev; float div;                  // out = (result + out) / div
+  int terms;                                // 3 = split product, 1 = plain f16 operands
+  int tiles;                                // set by the launcher: tiles per utterance
+};
+bool cl_pair_supported(int C, int K, int dil);
+hipError_t launch_cl_pair(const ClPairArgs& a, int B, hipStream_t s);
 size_t packed_cl_halfs(int Cout, int Cin, int K, int phases);
 void pack_cl_weights(uint16_t* hi, uint16_t* lo, int Cout, int Cin, int K, int phases, const float* dense);
 hipError_t launch_transpose_ct(const float* x, long x_bs, long x_cs, float* y, long y_bs, int y_ts, int B, int C,

@@ -1,0 +1,331 @@
+// One launch per ResBlock1 conv PAIR of the 32- and 64-channel vocoder stages (reference
+// modules.py:210-223):
+//     y = x + conv2(lrelu(conv1(lrelu(x), dilation d) + b1), dilation 1) + b2
+// on channels-last fp32 activations [B][T][C], C = 32 * NT.  These stages are HBM-bound (SURVEY.md
+// section 8d: 76 % of the vocoder's layer-boundary bytes); run as two launches of cl_conv_f16s the
+// pair moves x, t, t, x, y through HBM (5 passes).  Here the intermediate t never leaves the CU:
+//   1. the block stages its x window (256 + (K-1)*d rows, one 32-channel chunk at a time), activated
+//      and split to f16 hi/lo images in LDS, and runs conv1 on the matrix core for 256 rows;
+//   2. the conv1 tile (bias added, rows outside the utterance zeroed = conv2's zero padding) is
+//      activated, split and written over the dead x window as conv2's input image;
+//   3. conv2 produces 256 - (K-1) output rows; the residual x rows are re-read (L2) and y stored.
+// Arithmetic (split-f16 products, accumulation order per conv) is that of cl_conv_f16s, so the result
+// is bit-identical to the two-launch path.  Weights stream through the same double-buffered LDS ring,
+// one continuous sequence of slices across both convs.  Tiles are numbered so that neighbours (which
+// share halo rows and whose residual rows were just read) run on the same XCD / L2.
+#include "kernels.h"
+
+#include <cstdlib>
+
+namespace vsp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int RP_BT = 256;     // conv1 rows per block (8 waves x 32)
+constexpr int RP_HALO = 64;    // max (K-1)*dil
+constexpr int RP_CKC = 32;     // input channels per chunk
+constexpr int RP_RS = RP_CKC + 8;
+
+template <int NT, int G, int TERMS, bool PF>
+__global__ void __launch_bounds__(512, 4) cl_respair_f16s(ClPairArgs a) {
+  constexpr int CKC = RP_CKC, RS = RP_RS, NTH = 512, C = 32 * NT;
+  constexpr int C4 = CKC / 4;                    // float4 per staged row
+  constexpr int ROWS_PER_U = NTH / C4;           // 64 rows per staging sweep
+  constexpr int NL = (RP_BT + RP_HALO + ROWS_PER_U - 1) / ROWS_PER_U;
+  constexpr int WMAX = NL * ROWS_PER_U;          // 320 staged rows
+  constexpr int KS = CKC / 16;
+  constexpr int XIMG = WMAX * RS;                // halfs per activation image
+  constexpr int WIMG = G * KS * NT * 64 * 8;     // halfs per weight-slice image
+  constexpr int NWV = NTH / 64;
+  constexpr int NBLK = (TERMS == 3 ? 2 : 1) * G * KS * NT;
+  constexpr int NWL = (NBLK + NWV - 1) / NWV;
+  constexpr int NCH = NT;                        // 32-channel chunks of the contraction
+  extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+  _Float16* const Xh = lds;                      // [WMAX][RS] hi, then lo: x window, later the t image
+  _Float16* const Wb = lds + 2 * XIMG;
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int row0 = wave * 32;
+
+  // XCD-aware tile numbering: workgroup ids go round-robin over the 8 XCDs, so give XCD k the k-th
+  // contiguous eighth of the (utterance, tile) sequence (bijective for any grid size)
+  const int nwg = gridDim.x, orig = blockIdx.x;
+  const int xcd = orig & 7, q = nwg >> 3, rem = nwg & 7;
+  const int id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (orig >> 3);
+  const int b = id / a.tiles, tile = id - b * a.tiles;
+
+  const int K = a.K, p2 = (K - 1) >> 1, p1 = a.dil * p2;
+  const int R2 = RP_BT - (K - 1);                // output rows per block
+  const int t0 = tile * R2;                      // first output row
+  const int ns = (K + G - 1) / G;                // weight slices per chunk
+  const int nsteps1 = NCH * ns;
+
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x) + (size_t)b * a.x_bs, 0, a.T * C * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)b * a.o_bs, 0, a.T * C * 4,
+                                                                      0x00020000);
+
+  // ---- x window staging (as in cl_conv_f16s): row 0 of the window is time t0 - p2 - p1
+  const int st_row = tid / C4, st_c4 = tid % C4;
+  const int st_voff = (st_row * C + 4 * st_c4) * 4;
+  const int st_loff = st_row * RS + 4 * st_c4;
+  u32x4 sv[NL];
+  const float slope = a.slope;
+  auto x_issue = [&](int chunk) {
+    const int base = ((t0 - p2 - p1) * C + chunk * CKC) * 4;
+#pragma unroll
+    for (int u = 0; u < NL; ++u)
+      sv[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, st_voff + (base + u * ROWS_PER_U * C * 4), 0, 0);
+  };
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+  auto x_write = [&]() {
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+      f16x4 eh, el;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        f32x2 x = {__uint_as_float(k == 0 ? sv[u].x : sv[u].z), __uint_as_float(k == 0 ? sv[u].y : sv[u].w)};
+        const f32x2 y = x * slope;
+        asm("v_max_f32 %0, %1, %2" : "=v"(x.x) : "v"(x.x), "v"(y.x));
+        asm("v_max_f32 %0, %1, %2" : "=v"(x.y) : "v"(x.y), "v"(y.y));
+        const f16x2 xh = __builtin_convertvector(x, f16x2);
+        const f32x2 back = __builtin_convertvector(xh, f32x2);
+        const f16x2 xl = __builtin_convertvector((x - back) * 2048.f, f16x2);
+        eh[2 * k] = xh.x; eh[2 * k + 1] = xh.y;
+        el[2 * k] = xl.x; el[2 * k + 1] = xl.y;
+      }
+      _Float16* dst = Xh + st_loff + u * (ROWS_PER_U * RS);
+      *reinterpret_cast<f16x4*>(dst) = eh;
+      if constexpr (TERMS == 3) *reinterpret_cast<f16x4*>(dst + XIMG) = el;
+    }
+  };
+
+  // ---- weight slices: step s in [0, 2*nsteps1): conv = s / nsteps1, then (chunk, slice) as in
+  //      cl_conv_f16s; fragment-block index ((img*G + g)*KS + ks)*NT + ntl is wave-uniform
+  const int nks = C >> 4;
+  uint4 wq[NWL];
+  auto w_issue = [&](int step) {
+    const int cv = step >= nsteps1 ? 1 : 0;
+    const int s1 = step - cv * nsteps1;
+    const int chunk = s1 / ns, sl = s1 - chunk * ns;
+    const uint4* WHg = reinterpret_cast<const uint4*>(cv ? a.w2h : a.w1h);
+    const uint4* WLg = reinterpret_cast<const uint4*>(cv ? a.w2l : a.w1l);
+#pragma unroll
+    for (int u = 0; u < NWL; ++u) {
+      const int blk = u * NWV + wave;
+      const int ntl = blk % NT, ks = (blk / NT) % KS, g = (blk / (NT * KS)) % G, img = blk / (NT * KS * G);
+      const int tap = sl * G + g;
+      wq[u] = make_uint4(0u, 0u, 0u, 0u);
+      if (blk < NBLK && tap < K) {
+        const size_t src = (((size_t)tap * nks + chunk * KS + ks) * NT + ntl) * 64;
+        wq[u] = (img == 0 ? WHg : WLg)[src + lane];
+      }
+    }
+  };
+  auto w_write = [&](int buf) {
+    uint4* dst = reinterpret_cast<uint4*>(Wb + buf * 2 * WIMG) + tid;
+#pragma unroll
+    for (int u = 0; u < NWL; ++u)
+      if (u * NWV + wave < NBLK) dst[u * NTH] = wq[u];
+  };
+
+  // ---- fragments
+  const int xf_lane = (row0 + l31) * RS + 8 * h;
+  const int wf_lane = lane * 8;
+  auto load_frags = [&](const _Float16* Wc, int rowoff, int it, f16x8& xh, f16x8& xl, f16x8(&wh)[NT], f16x8(&wl)[NT]) {
+    const int g = it / KS, ks = it % KS;
+    const _Float16* px = Xh + xf_lane + (rowoff * RS + ks * 16);
+    xh = *reinterpret_cast<const f16x8*>(px);
+    if constexpr (TERMS == 3) xl = *reinterpret_cast<const f16x8*>(px + XIMG);
+    const _Float16* pw = Wc + wf_lane + (g * KS + ks) * NT * 512;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      wh[nt] = *reinterpret_cast<const f16x8*>(pw + nt * 512);
+      if constexpr (TERMS == 3) wl[nt] = *reinterpret_cast<const f16x8*>(pw + nt * 512 + WIMG);
+    }
+  };
+  f32x16 hh[NT], cr[NT];
+  auto mma = [&](const f16x8& xh, const f16x8& xl, const f16x8(&wh)[NT], const f16x8(&wl)[NT]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) hh[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh[nt], hh[nt], 0, 0, 0);
+    if constexpr (TERMS == 3) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) cr[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wl[nt], cr[nt], 0, 0, 0);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) cr[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wh[nt], cr[nt], 0, 0, 0);
+    }
+  };
+  auto init_acc = [&](const float* bias) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const float bv = bias[nt * 32 + l31];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { hh[nt][r] = bv; cr[nt][r] = 0.f; }
+    }
+  };
+  // MFMAs of one weight slice; rowstep = dilation of the conv the slice belongs to
+  // PF: fragments one k-step ahead of the MFMAs (two register sets); otherwise the SIMD's other
+  // waves cover the LDS latency (the 64-channel tile has no registers to spare)
+  f16x8 xhA, xlA, whA[NT], wlA[NT];
+  [[maybe_unused]] f16x8 xhB, xlB, whB[NT], wlB[NT];
+  auto slice = [&](int step, int sl, int rowstep) {
+    const _Float16* Wc = Wb + (step & 1) * 2 * WIMG;
+    const int tap0 = sl * G;
+    const int nit = ((K - tap0) < G ? (K - tap0) : G) * KS;
+    if constexpr (PF) {
+      load_frags(Wc, tap0 * rowstep, 0, xhA, xlA, whA, wlA);
+      for (int it = 0; it < nit; it += 2) {
+        if (it + 1 < nit) load_frags(Wc, (tap0 + (it + 1) / KS) * rowstep, it + 1, xhB, xlB, whB, wlB);
+        mma(xhA, xlA, whA, wlA);
+        if (it + 1 < nit) {
+          if (it + 2 < nit) load_frags(Wc, (tap0 + (it + 2) / KS) * rowstep, it + 2, xhA, xlA, whA, wlA);
+          mma(xhB, xlB, whB, wlB);
+        }
+      }
+    } else {
+      for (int it = 0; it < nit; ++it) {
+        load_frags(Wc, (tap0 + it / KS) * rowstep, it, xhA, xlA, whA, wlA);
+        mma(xhA, xlA, whA, wlA);
+      }
+    }
+  };
+
+  // ================= conv1 =================
+  init_acc(a.b1);
+  x_issue(0);
+  w_issue(0);
+  x_write();
+  w_write(0);
+  __syncthreads();
+  for (int step = 0; step < nsteps1; ++step) {
+    const int chunk = step / ns, sl = step - chunk * ns;
+    const bool new_chunk = (NCH > 1) && sl == ns - 1 && chunk + 1 < NCH;
+    w_issue(step + 1);                          // conv2's first slice follows conv1's last
+    if (new_chunk) x_issue(chunk + 1);
+    slice(step, sl, a.dil);
+    if (new_chunk) {
+      __syncthreads();                          // every wave is done reading this chunk's window
+      x_write();
+    }
+    w_write((step + 1) & 1);
+    __syncthreads();
+  }
+
+  // conv1 tile -> fp32 values (bias is in hh), rows outside the utterance are conv2's zero padding
+  float tv[NT][16];
+  {
+    const int tt = t0 - p2 + row0 + 4 * h;      // time of D register 0 of this lane
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int t = tt + (r & 3) + 8 * (r >> 2);
+        float v = TERMS == 3 ? hh[nt][r] + cr[nt][r] * (1.f / 2048.f) : hh[nt][r];
+        const float y = v * slope;
+        v = v > y ? v : y;                      // leaky-relu (0 <= slope <= 1)
+        tv[nt][r] = (t >= 0 && t < a.T) ? v : 0.f;
+      }
+  }
+
+  // ================= conv2 =================
+  init_acc(a.b2);
+  const int nsteps = 2 * nsteps1;
+  for (int c2 = 0; c2 < NCH; ++c2) {
+    // t image chunk c2 = conv1 output channels [32*c2, 32*c2+32): lane = channel, register = row.
+    // (the barrier closing the previous step guarantees that nobody still reads the region)
+    {
+      _Float16* dst = Xh + (row0 + 4 * h) * RS + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = tv[c2][r];
+        const _Float16 vh = (_Float16)v;
+        dst[((r & 3) + 8 * (r >> 2)) * RS] = vh;
+        if constexpr (TERMS == 3) dst[((r & 3) + 8 * (r >> 2)) * RS + XIMG] = (_Float16)((v - (float)vh) * 2048.f);
+      }
+    }
+    __syncthreads();
+    for (int sl = 0; sl < ns; ++sl) {
+      const int step = nsteps1 + c2 * ns + sl;
+      const bool more = step + 1 < nsteps;
+      if (more) w_issue(step + 1);
+      slice(step, sl, 1);
+      if (more) {
+        w_write((step + 1) & 1);
+        __syncthreads();
+      }
+    }
+  }
+
+  // ---- epilogue: y = conv2 + x (+ previous resblock sum) (/ div); rows >= R2 belong to the next tile
+  const int ts = C * 4;                          // bytes per row
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int lo = (t0 + row0 + 4 * h) * ts + (nt * 32 + l31) * 4;
+    int off[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rr = (r & 3) + 8 * (r >> 2);
+      off[r] = (row0 + 4 * h + rr) < R2 ? lo + rr * ts : 0x7ffffff0;   // out of range: load 0 / store dropped
+    }
+    float v[16], rv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, off[r], 0, 0));
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      v[r] = (TERMS == 3 ? hh[nt][r] + cr[nt][r] * (1.f / 2048.f) : hh[nt][r]) + rv[r];
+    if (a.acc_prev) {
+      float pv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ro, off[r], 0, 0));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] += pv[r];
+    }
+    if (a.div != 1.f) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] /= a.div;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), ro, off[r], 0, 0);
+  }
+}
+
+template <int NT, int G, int TERMS, bool PF>
+static hipError_t launch_pair_tile(ClPairArgs a, int B, hipStream_t s) {
+  constexpr int NLc = (RP_BT + RP_HALO + 63) / 64;
+  constexpr size_t lds = ((size_t)2 * NLc * 64 * RP_RS + (size_t)4 * G * (RP_CKC / 16) * NT * 512) * sizeof(_Float16);
+  static_assert(lds <= 80 * 1024, "two blocks per CU");
+  static bool attr_set = false;
+  auto kern = cl_respair_f16s<NT, G, TERMS, PF>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int R2 = RP_BT - (a.K - 1);
+  a.tiles = (a.T + R2 - 1) / R2;
+  const long n = (long)a.tiles * B;
+  if (n <= 0 || n > 0x7fffffffL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(512), lds, s, a);
+  return hipGetLastError();
+}
+
+bool cl_pair_supported(int C, int K, int dil) {
+  return (C == 32 || C == 64) && K >= 1 && (K & 1) && (K - 1) * dil <= RP_HALO && K - 1 < RP_BT / 2;
+}
+
+hipError_t launch_cl_pair(const ClPairArgs& a, int B, hipStream_t s) {
+  if (!cl_pair_supported(a.C, a.K, a.dil) || a.T <= 0 || B <= 0 || (a.x_bs & 3) ||
+      (reinterpret_cast<uintptr_t>(a.x) & 15) || a.x == a.out)
+    return hipErrorInvalidValue;
+  if (a.terms == 1) return a.C == 32 ? launch_pair_tile<1, 2, 1, true>(a, B, s) : launch_pair_tile<2, 1, 1, true>(a, B, s);
+  return a.C == 32 ? launch_pair_tile<1, 2, 3, true>(a, B, s) : launch_pair_tile<2, 1, 3, false>(a, B, s);
+}
+
+}  // namespace vsp
