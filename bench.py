@@ -192,9 +192,10 @@ def main():
             else:
                 roof = {"bound": "mfma", "achieved": 3.0 * tfl, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": f_mfma}
-            roof.update({"traffic": None, "kernel": "cl_conv_f16s (generator launches, rank 0)",
+            roof.update({"traffic": None,
+                         "kernel": "generator convolutions: cl_conv_f16s + cl_respair_f16s (fused ResBlock pairs), rank 0",
                          "alg_tflops": tfl, "alg_gbs": gbs, "hbm_frac": f_hbm, "mfma_issue_frac": f_mfma,
-                         "note": "fp32 activations in HBM; f16 MFMA on split operands (3 MFMA per product), fp32-accurate"})
+                         "note": "fp32 activations in HBM; f16 MFMA on split operands (3 MFMA per product), fp32-accurate; achieved counts the layer-boundary bytes of SURVEY 8d for every conv, also for the fused pairs whose intermediate never reaches HBM (so traffic < algorithmic bytes there)"})
             dtype = "f32 (split-f16 MFMA, 3-term)"
             if gen_mode == "f16":      # opt-in reduced precision: NOT the headline configuration
                 dtype = "f16 operands, f32 accumulate (VSP_GENERATOR=f16: reduced precision, fails the fp32 parity gate)"

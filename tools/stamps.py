@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Phase timeline of one cl_respair_f16s launch from the in-kernel stamps of the VSP_STAMPS build.
+usage (GPU box): VSP_LIB_PATH=build/stamps/libvispeech_hip.so VSP_STAMP_LAUNCH=<n> python tools/stamps.py
+n = 0-based index of the pair launch PER TILE TYPE in the first generator call: 0..8 = (k3 d1,d3,d5, k7 ..., k11 ...)
+of the 64-channel stage and, in the same run, of the 32-channel stage (the two are told apart by stamp count).
+Stamp order: start | loads issued | window written | barrier | per conv1 step: MFMAs done, next slice written, barrier |
+t image written, barrier | per conv2 step: MFMAs done, slice written, barrier | epilogue start | end."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vispeech_amd import _lib, config as vcfg           # noqa: E402
+from vispeech_amd.models import SynthesizerTrn          # noqa: E402
+from vispeech_amd.schema import ModelDims               # noqa: E402
+from vispeech_amd.synth import synth_state_dict         # noqa: E402
+
+dims = ModelDims()
+a, kw = vcfg.synthesizer_args(vcfg.default_hparams())
+net = SynthesizerTrn(*a, **kw).eval()
+net.load_state_dict(synth_state_dict(dims, seed=1234, infer_only=True))
+B, T = 64, 489
+r = np.random.Generator(np.random.PCG64(1))
+z = torch.from_numpy(r.standard_normal((B, dims.inter_channels, T)).astype(np.float32)).cuda()
+g = torch.from_numpy(r.standard_normal((B, dims.gin_channels)).astype(np.float32)).cuda()
+net._engine.generator(z, g)
+torch.cuda.synchronize()
+lib = _lib.lib()
+fn = lib.vsp_debug_stamps
+fn.restype = C.c_int
+NS, NSTAMP = 256, 64
+buf = np.zeros((NS, NSTAMP), dtype=np.uint64)
+n = fn(buf.ctypes.data_as(C.c_void_p), NS, 1)
+print(f"pair launch #{os.environ.get('VSP_STAMP_LAUNCH')} of each tile type: {n} sampled blocks (wave 0); stamps are 100 MHz wall clock")
+s = buf[:n].astype(np.int64)
+counts = (s > 0).sum(axis=1)
+for cnt in sorted(set(counts.tolist())):
+    g = s[counts == cnt][:, :cnt]
+    rel = (g - g[:, :1]) / 100.0                  # us since block start
+    med = np.median(rel, axis=0)
+    d = np.diff(med)
+    print(f"-- {len(g)} blocks with {cnt} stamps: block lifetime median {med[-1]:.2f} us "
+          f"(p10 {np.percentile(rel[:, -1], 10):.2f}, p90 {np.percentile(rel[:, -1], 90):.2f})")
+    print("   deltas us:", " ".join(f"{x:.2f}" for x in d))

@@ -3,13 +3,13 @@
 WRITE_SIZE collected separately, as MI355X_MICROARCH.md prescribes: FETCH_SIZE takes 3 of the 4 TCC
 slots, WRITE_SIZE 2).  Units are KiB; on gfx950 FETCH_SIZE reports exactly half of the bytes of a
 wide (16 B/lane) coalesced streaming read, so the read side is doubled; WRITE_SIZE is taken as is.
-usage: traffic_from_pmc.py <kernel substr> <fetch counter_collection.csv> <write counter_collection.csv> <generator> <utterances>"""
+usage: traffic_from_pmc.py <kernel substr[|substr...]> <fetch counter_collection.csv> <write counter_collection.csv> <generator> <utterances>"""
 import csv, json, sys
 sub, fcsv, wcsv, gen, utt = sys.argv[1:6]
 def total(path, counter):
     s = 0.0; n = 0
     for r in csv.DictReader(open(path)):
-        if sub in r['Kernel_Name'] and r['Counter_Name'] == counter:
+        if any(x in r['Kernel_Name'] for x in sub.split('|')) and r['Counter_Name'] == counter:
             s += float(r['Counter_Value']); n += 1
     return s, n
 f, nf = total(fcsv, 'FETCH_SIZE')

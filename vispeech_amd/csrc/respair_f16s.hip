@@ -24,6 +24,34 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// VSP_DIAG: timing-only ablation builds (tools/ablate.sh; results wrong by construction): bit 0 no MFMA,
+// bit 1 no weight-slice loads, bit 2 no activation loads, bit 3 no epilogue memory traffic, bit 4 no
+// barriers, bit 5 no LDS fragment reads.  0 in the product build.
+#ifndef VSP_DIAG
+#define VSP_DIAG 0
+#endif
+#if VSP_DIAG & 16
+#define RP_SYNC() ((void)0)
+#else
+#define RP_SYNC() __syncthreads()
+#endif
+
+// VSP_STAMPS (diagnostic build, tools/stamps.py): wave 0 of every 509th block records wall-clock stamps
+// (s_memrealtime, 100 MHz) at its phase boundaries into a device array read back by vsp_debug_stamps.
+#ifdef VSP_STAMPS
+constexpr int RP_NSTAMP = 64, RP_NSAMPLE = 256;
+__device__ unsigned long long g_stamps[RP_NSAMPLE][RP_NSTAMP];
+__device__ unsigned g_stamp_count;
+#define RP_STAMP()                                                          \
+  do {                                                                      \
+    if (stamp_slot >= 0 && stamp_n < RP_NSTAMP && lane == 0)                \
+      g_stamps[stamp_slot][stamp_n] = __builtin_amdgcn_s_memrealtime();     \
+    ++stamp_n;                                                              \
+  } while (0)
+#else
+#define RP_STAMP() ((void)0)
+#endif
+
 constexpr int RP_BT = 256;     // conv1 rows per block (8 waves x 32)
 constexpr int RP_HALO = 64;    // max (K-1)*dil
 constexpr int RP_CKC = 32;     // input channels per chunk
@@ -59,6 +87,16 @@ __global__ void __launch_bounds__(512, 4) cl_respair_f16s(ClPairArgs a) {
   const int id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (orig >> 3);
   const int b = id / a.tiles, tile = id - b * a.tiles;
 
+#ifdef VSP_STAMPS
+  int stamp_slot = -1, stamp_n = 0;
+  if (wave == 0 && orig % 509 == 7 && (a.terms & 0x100)) {
+    unsigned sl_ = 0;
+    if (lane == 0) sl_ = atomicAdd(&g_stamp_count, 1u);
+    sl_ = __builtin_amdgcn_readfirstlane(sl_);
+    stamp_slot = sl_ < (unsigned)RP_NSAMPLE ? (int)sl_ : -1;
+  }
+  RP_STAMP();                                   // 0: start
+#endif
   const int K = a.K, p2 = (K - 1) >> 1, p1 = a.dil * p2;
   const int R2 = RP_BT - (K - 1);                // output rows per block
   const int t0 = tile * R2;                      // first output row
@@ -80,7 +118,8 @@ __global__ void __launch_bounds__(512, 4) cl_respair_f16s(ClPairArgs a) {
     const int base = ((t0 - p2 - p1) * C + chunk * CKC) * 4;
 #pragma unroll
     for (int u = 0; u < NL; ++u)
-      sv[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, st_voff + (base + u * ROWS_PER_U * C * 4), 0, 0);
+      sv[u] = (VSP_DIAG & 4) ? u32x4{1u, 2u, 3u, 4u}
+                             : __builtin_amdgcn_raw_buffer_load_b128(rx, st_voff + (base + u * ROWS_PER_U * C * 4), 0, 0);
   };
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -122,7 +161,7 @@ __global__ void __launch_bounds__(512, 4) cl_respair_f16s(ClPairArgs a) {
       const int ntl = blk % NT, ks = (blk / NT) % KS, g = (blk / (NT * KS)) % G, img = blk / (NT * KS * G);
       const int tap = sl * G + g;
       wq[u] = make_uint4(0u, 0u, 0u, 0u);
-      if (blk < NBLK && tap < K) {
+      if (blk < NBLK && tap < K && (VSP_DIAG & 2) == 0) {
         const size_t src = (((size_t)tap * nks + chunk * KS + ks) * NT + ntl) * 64;
         wq[u] = (img == 0 ? WHg : WLg)[src + lane];
       }
@@ -139,6 +178,12 @@ __global__ void __launch_bounds__(512, 4) cl_respair_f16s(ClPairArgs a) {
   const int xf_lane = (row0 + l31) * RS + 8 * h;
   const int wf_lane = lane * 8;
   auto load_frags = [&](const _Float16* Wc, int rowoff, int it, f16x8& xh, f16x8& xl, f16x8(&wh)[NT], f16x8(&wl)[NT]) {
+    if constexpr ((VSP_DIAG & 32) != 0) {
+      asm volatile("" : "=v"(xh), "=v"(xl));
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) asm volatile("" : "=v"(wh[nt]), "=v"(wl[nt]));
+      return;
+    }
     const int g = it / KS, ks = it % KS;
     const _Float16* px = Xh + xf_lane + (rowoff * RS + ks * 16);
     xh = *reinterpret_cast<const f16x8*>(px);
@@ -152,6 +197,12 @@ __global__ void __launch_bounds__(512, 4) cl_respair_f16s(ClPairArgs a) {
   };
   f32x16 hh[NT], cr[NT];
   auto mma = [&](const f16x8& xh, const f16x8& xl, const f16x8(&wh)[NT], const f16x8(&wl)[NT]) {
+    if constexpr ((VSP_DIAG & 1) != 0) {
+      asm volatile("" ::"v"(xh), "v"(xl));
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) asm volatile("" ::"v"(wh[nt]), "v"(wl[nt]));
+      return;
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) hh[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh[nt], hh[nt], 0, 0, 0);
     if constexpr (TERMS == 3) {
@@ -200,21 +251,27 @@ __global__ void __launch_bounds__(512, 4) cl_respair_f16s(ClPairArgs a) {
   init_acc(a.b1);
   x_issue(0);
   w_issue(0);
+  RP_STAMP();                                   // 1: loads issued
   x_write();
   w_write(0);
-  __syncthreads();
+  RP_STAMP();                                   // 2: window converted + written (includes the load latency)
+  RP_SYNC();
+  RP_STAMP();                                   // 3: barrier
   for (int step = 0; step < nsteps1; ++step) {
     const int chunk = step / ns, sl = step - chunk * ns;
     const bool new_chunk = (NCH > 1) && sl == ns - 1 && chunk + 1 < NCH;
     w_issue(step + 1);                          // conv2's first slice follows conv1's last
     if (new_chunk) x_issue(chunk + 1);
     slice(step, sl, a.dil);
+    RP_STAMP();                                 // conv1 step: MFMAs done
     if (new_chunk) {
-      __syncthreads();                          // every wave is done reading this chunk's window
+      RP_SYNC();                          // every wave is done reading this chunk's window
       x_write();
     }
     w_write((step + 1) & 1);
-    __syncthreads();
+    RP_STAMP();                                 // conv1 step: next slice written (includes its fetch latency)
+    RP_SYNC();
+    RP_STAMP();                                 // conv1 step: barrier
   }
 
   // conv1 tile -> fp32 values (bias is in hh), rows outside the utterance are conv2's zero padding
@@ -249,19 +306,25 @@ __global__ void __launch_bounds__(512, 4) cl_respair_f16s(ClPairArgs a) {
         if constexpr (TERMS == 3) dst[((r & 3) + 8 * (r >> 2)) * RS + XIMG] = (_Float16)((v - (float)vh) * 2048.f);
       }
     }
-    __syncthreads();
+    RP_STAMP();                                 // t image written
+    RP_SYNC();
+    RP_STAMP();                                 // barrier
     for (int sl = 0; sl < ns; ++sl) {
       const int step = nsteps1 + c2 * ns + sl;
       const bool more = step + 1 < nsteps;
       if (more) w_issue(step + 1);
       slice(step, sl, 1);
+      RP_STAMP();                               // conv2 step: MFMAs done
       if (more) {
         w_write((step + 1) & 1);
-        __syncthreads();
+        RP_STAMP();                             // conv2 step: next slice written
+        RP_SYNC();
+        RP_STAMP();                             // conv2 step: barrier
       }
     }
   }
 
+  RP_STAMP();                                   // epilogue start
   // ---- epilogue: y = conv2 + x (+ previous resblock sum) (/ div); rows >= R2 belong to the next tile
   const int ts = C * 4;                          // bytes per row
 #pragma unroll
@@ -275,11 +338,12 @@ __global__ void __launch_bounds__(512, 4) cl_respair_f16s(ClPairArgs a) {
     }
     float v[16], rv[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) rv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, off[r], 0, 0));
+    for (int r = 0; r < 16; ++r)
+      rv[r] = (VSP_DIAG & 8) ? 1.f : __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, off[r], 0, 0));
 #pragma unroll
     for (int r = 0; r < 16; ++r)
       v[r] = (TERMS == 3 ? hh[nt][r] + cr[nt][r] * (1.f / 2048.f) : hh[nt][r]) + rv[r];
-    if (a.acc_prev) {
+    if (a.acc_prev && (VSP_DIAG & 8) == 0) {
       float pv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) pv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ro, off[r], 0, 0));
@@ -290,10 +354,34 @@ __global__ void __launch_bounds__(512, 4) cl_respair_f16s(ClPairArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] /= a.div;
     }
+    if constexpr ((VSP_DIAG & 8) != 0) {
+      float sum = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), ro, off[r], 0, 0);
+      for (int r = 0; r < 16; ++r) sum += v[r];
+      if (sum == 1.2345e-30f) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sum), ro, off[0], 0, 0);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), ro, off[r], 0, 0);
+    }
   }
+#ifdef VSP_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  RP_STAMP();                                   // end (stores retired)
+#endif
 }
+
+#ifdef VSP_STAMPS
+extern "C" int vsp_debug_stamps(unsigned long long* host, int max_samples, int reset) {
+  unsigned n = 0;
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_stamp_count), sizeof n);
+  if ((int)n > max_samples) n = max_samples;
+  if (n > (unsigned)RP_NSAMPLE) n = RP_NSAMPLE;
+  (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), (size_t)n * RP_NSTAMP * sizeof(unsigned long long));
+  if (reset) { const unsigned z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_count), &z, sizeof z); }
+  return (int)n;
+}
+#endif
 
 template <int NT, int G, int TERMS, bool PF>
 static hipError_t launch_pair_tile(ClPairArgs a, int B, hipStream_t s) {
@@ -308,6 +396,14 @@ static hipError_t launch_pair_tile(ClPairArgs a, int B, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
+#ifdef VSP_STAMPS
+  {  // stamps only in the VSP_STAMP_LAUNCH-th pair launch of the process (0-based)
+    static int launch_no = 0;
+    static int target = -2;
+    if (target == -2) { const char* e = getenv("VSP_STAMP_LAUNCH"); target = e ? atoi(e) : -1; }
+    if (launch_no++ == target) a.terms |= 0x100;
+  }
+#endif
   const int R2 = RP_BT - (a.K - 1);
   a.tiles = (a.T + R2 - 1) / R2;
   const long n = (long)a.tiles * B;
