@@ -229,7 +229,23 @@ __global__ void __launch_bounds__(512, 4) cl_respair_f16s(ClPairArgs a) {
     const _Float16* Wc = Wb + (step & 1) * 2 * WIMG;
     const int tap0 = sl * G;
     const int nit = ((K - tap0) < G ? (K - tap0) : G) * KS;
-    if constexpr (PF) {
+    if constexpr (PF && NT == 1 && G * KS == 4) {
+      // 32-channel tile: registers to spare -- all fragments of the slice are requested before its
+      // first MFMA (one LDS round trip per slice instead of one per k-step: 3 MFMAs do not cover it)
+      f16x8 xhC, xlC, whC[NT], wlC[NT], xhD, xlD, whD[NT], wlD[NT];
+      load_frags(Wc, tap0 * rowstep, 0, xhA, xlA, whA, wlA);
+      load_frags(Wc, tap0 * rowstep, 1, xhB, xlB, whB, wlB);
+      if (nit > 2) {
+        load_frags(Wc, (tap0 + 1) * rowstep, 2, xhC, xlC, whC, wlC);
+        load_frags(Wc, (tap0 + 1) * rowstep, 3, xhD, xlD, whD, wlD);
+      }
+      mma(xhA, xlA, whA, wlA);
+      mma(xhB, xlB, whB, wlB);
+      if (nit > 2) {
+        mma(xhC, xlC, whC, wlC);
+        mma(xhD, xlD, whD, wlD);
+      }
+    } else if constexpr (PF) {
       load_frags(Wc, tap0 * rowstep, 0, xhA, xlA, whA, wlA);
       for (int it = 0; it < nit; it += 2) {
         if (it + 1 < nit) load_frags(Wc, (tap0 + (it + 1) / KS) * rowstep, it + 1, xhB, xlB, whB, wlB);
