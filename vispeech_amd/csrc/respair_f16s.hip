@@ -57,9 +57,12 @@ constexpr int RP_HALO = 64;    // max (K-1)*dil
 constexpr int RP_CKC = 32;     // input channels per chunk
 constexpr int RP_RS = RP_CKC + 8;
 
-template <int NT, int G, int TERMS, bool PF>
-__global__ void __launch_bounds__(512, 4) cl_respair_f16s(ClPairArgs a) {
-  constexpr int CKC = RP_CKC, RS = RP_RS, NTH = 512, C = 32 * NT;
+// MT = 32-row tiles per wave: 1 -> 8 waves per block (4 per SIMD with two blocks per CU, <= 128 VGPRs);
+// 2 -> 4 "fat" waves per block (2 per SIMD, up to 256 VGPRs: latency is hidden by prefetch inside the wave
+// instead of by the other waves, and only one wave of a block competes for a SIMD's matrix core)
+template <int NT, int G, int TERMS, bool PF, int MT>
+__global__ void __launch_bounds__(512 / MT, 4 / MT) cl_respair_f16s(ClPairArgs a) {
+  constexpr int CKC = RP_CKC, RS = RP_RS, NTH = 512 / MT, C = 32 * NT;
   constexpr int C4 = CKC / 4;                    // float4 per staged row
   constexpr int ROWS_PER_U = NTH / C4;           // 64 rows per staging sweep
   constexpr int NL = (RP_BT + RP_HALO + ROWS_PER_U - 1) / ROWS_PER_U;
@@ -78,7 +81,7 @@ __global__ void __launch_bounds__(512, 4) cl_respair_f16s(ClPairArgs a) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, l31 = lane & 31, h = lane >> 5;
-  const int row0 = wave * 32;
+  const int row0 = wave * 32 * MT;
 
   // XCD-aware tile numbering: workgroup ids go round-robin over the 8 XCDs, so give XCD k the k-th
   // contiguous eighth of the (utterance, tile) sequence (bijective for any grid size)
@@ -177,17 +180,22 @@ __global__ void __launch_bounds__(512, 4) cl_respair_f16s(ClPairArgs a) {
   // ---- fragments
   const int xf_lane = (row0 + l31) * RS + 8 * h;
   const int wf_lane = lane * 8;
-  auto load_frags = [&](const _Float16* Wc, int rowoff, int it, f16x8& xh, f16x8& xl, f16x8(&wh)[NT], f16x8(&wl)[NT]) {
+  auto load_frags = [&](const _Float16* Wc, int rowoff, int it, f16x8(&xh)[MT], f16x8(&xl)[MT], f16x8(&wh)[NT],
+                        f16x8(&wl)[NT]) {
     if constexpr ((VSP_DIAG & 32) != 0) {
-      asm volatile("" : "=v"(xh), "=v"(xl));
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) asm volatile("" : "=v"(xh[mt]), "=v"(xl[mt]));
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) asm volatile("" : "=v"(wh[nt]), "=v"(wl[nt]));
       return;
     }
     const int g = it / KS, ks = it % KS;
     const _Float16* px = Xh + xf_lane + (rowoff * RS + ks * 16);
-    xh = *reinterpret_cast<const f16x8*>(px);
-    if constexpr (TERMS == 3) xl = *reinterpret_cast<const f16x8*>(px + XIMG);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      xh[mt] = *reinterpret_cast<const f16x8*>(px + mt * 32 * RS);
+      if constexpr (TERMS == 3) xl[mt] = *reinterpret_cast<const f16x8*>(px + mt * 32 * RS + XIMG);
+    }
     const _Float16* pw = Wc + wf_lane + (g * KS + ks) * NT * 512;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -195,21 +203,32 @@ __global__ void __launch_bounds__(512, 4) cl_respair_f16s(ClPairArgs a) {
       if constexpr (TERMS == 3) wl[nt] = *reinterpret_cast<const f16x8*>(pw + nt * 512 + WIMG);
     }
   };
-  f32x16 hh[NT], cr[NT];
-  auto mma = [&](const f16x8& xh, const f16x8& xl, const f16x8(&wh)[NT], const f16x8(&wl)[NT]) {
+  f32x16 hh[MT][NT], cr[MT][NT];
+  auto mma = [&](const f16x8(&xh)[MT], const f16x8(&xl)[MT], const f16x8(&wh)[NT], const f16x8(&wl)[NT]) {
     if constexpr ((VSP_DIAG & 1) != 0) {
-      asm volatile("" ::"v"(xh), "v"(xl));
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) asm volatile("" ::"v"(xh[mt]), "v"(xl[mt]));
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) asm volatile("" ::"v"(wh[nt]), "v"(wl[nt]));
       return;
     }
+    // tile-interleaved: the two MFMAs that chain on one CROSS accumulator are never back to back when MT*NT > 1
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) hh[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh[nt], hh[nt], 0, 0, 0);
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        hh[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[mt], wh[nt], hh[mt][nt], 0, 0, 0);
     if constexpr (TERMS == 3) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) cr[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wl[nt], cr[nt], 0, 0, 0);
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) cr[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wh[nt], cr[nt], 0, 0, 0);
+        for (int nt = 0; nt < NT; ++nt)
+          cr[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[mt], wl[nt], cr[mt][nt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          cr[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[mt], wh[nt], cr[mt][nt], 0, 0, 0);
     }
   };
   auto init_acc = [&](const float* bias) {
@@ -217,22 +236,24 @@ __global__ void __launch_bounds__(512, 4) cl_respair_f16s(ClPairArgs a) {
     for (int nt = 0; nt < NT; ++nt) {
       const float bv = bias[nt * 32 + l31];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { hh[nt][r] = bv; cr[nt][r] = 0.f; }
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { hh[mt][nt][r] = bv; cr[mt][nt][r] = 0.f; }
     }
   };
   // MFMAs of one weight slice; rowstep = dilation of the conv the slice belongs to
   // PF: fragments one k-step ahead of the MFMAs (two register sets); otherwise the SIMD's other
   // waves cover the LDS latency (the 64-channel tile has no registers to spare)
-  f16x8 xhA, xlA, whA[NT], wlA[NT];
-  [[maybe_unused]] f16x8 xhB, xlB, whB[NT], wlB[NT];
+  f16x8 xhA[MT], xlA[MT], whA[NT], wlA[NT];
+  [[maybe_unused]] f16x8 xhB[MT], xlB[MT], whB[NT], wlB[NT];
   auto slice = [&](int step, int sl, int rowstep) {
     const _Float16* Wc = Wb + (step & 1) * 2 * WIMG;
     const int tap0 = sl * G;
     const int nit = ((K - tap0) < G ? (K - tap0) : G) * KS;
-    if constexpr (PF && NT == 1 && G * KS == 4) {
+    if constexpr (PF && (NT == 1 || MT == 2) && G * KS == 4) {
       // 32-channel tile: registers to spare -- all fragments of the slice are requested before its
       // first MFMA (one LDS round trip per slice instead of one per k-step: 3 MFMAs do not cover it)
-      f16x8 xhC, xlC, whC[NT], wlC[NT], xhD, xlD, whD[NT], wlD[NT];
+      f16x8 xhC[MT], xlC[MT], whC[NT], wlC[NT], xhD[MT], xlD[MT], whD[NT], wlD[NT];
       load_frags(Wc, tap0 * rowstep, 0, xhA, xlA, whA, wlA);
       load_frags(Wc, tap0 * rowstep, 1, xhB, xlB, whB, wlB);
       if (nit > 2) {
@@ -291,19 +312,21 @@ __global__ void __launch_bounds__(512, 4) cl_respair_f16s(ClPairArgs a) {
   }
 
   // conv1 tile -> fp32 values (bias is in hh), rows outside the utterance are conv2's zero padding
-  float tv[NT][16];
+  float tv[MT][NT][16];
   {
-    const int tt = t0 - p2 + row0 + 4 * h;      // time of D register 0 of this lane
+    const int tt = t0 - p2 + row0 + 4 * h;      // time of D register 0 of this lane (tile mt adds 32*mt)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int t = tt + (r & 3) + 8 * (r >> 2);
-        float v = TERMS == 3 ? hh[nt][r] + cr[nt][r] * (1.f / 2048.f) : hh[nt][r];
-        const float y = v * slope;
-        v = v > y ? v : y;                      // leaky-relu (0 <= slope <= 1)
-        tv[nt][r] = (t >= 0 && t < a.T) ? v : 0.f;
-      }
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int t = tt + mt * 32 + (r & 3) + 8 * (r >> 2);
+          float v = TERMS == 3 ? hh[mt][nt][r] + cr[mt][nt][r] * (1.f / 2048.f) : hh[mt][nt][r];
+          const float y = v * slope;
+          v = v > y ? v : y;                    // leaky-relu (0 <= slope <= 1)
+          tv[mt][nt][r] = (t >= 0 && t < a.T) ? v : 0.f;
+        }
   }
 
   // ================= conv2 =================
@@ -312,11 +335,12 @@ __global__ void __launch_bounds__(512, 4) cl_respair_f16s(ClPairArgs a) {
   for (int c2 = 0; c2 < NCH; ++c2) {
     // t image chunk c2 = conv1 output channels [32*c2, 32*c2+32): lane = channel, register = row.
     // (the barrier closing the previous step guarantees that nobody still reads the region)
-    {
-      _Float16* dst = Xh + (row0 + 4 * h) * RS + l31;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      _Float16* dst = Xh + (row0 + mt * 32 + 4 * h) * RS + l31;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float v = tv[c2][r];
+        const float v = tv[mt][c2][r];
         const _Float16 vh = (_Float16)v;
         dst[((r & 3) + 8 * (r >> 2)) * RS] = vh;
         if constexpr (TERMS == 3) dst[((r & 3) + 8 * (r >> 2)) * RS + XIMG] = (_Float16)((v - (float)vh) * 2048.f);
@@ -344,13 +368,14 @@ __global__ void __launch_bounds__(512, 4) cl_respair_f16s(ClPairArgs a) {
   // ---- epilogue: y = conv2 + x (+ previous resblock sum) (/ div); rows >= R2 belong to the next tile
   const int ts = C * 4;                          // bytes per row
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int lo = (t0 + row0 + 4 * h) * ts + (nt * 32 + l31) * 4;
+  for (int mn = 0; mn < MT * NT; ++mn) {
+    const int mt = mn / NT, nt = mn % NT;
+    const int lo = (t0 + row0 + mt * 32 + 4 * h) * ts + (nt * 32 + l31) * 4;
     int off[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int rr = (r & 3) + 8 * (r >> 2);
-      off[r] = (row0 + 4 * h + rr) < R2 ? lo + rr * ts : 0x7ffffff0;   // out of range: load 0 / store dropped
+      off[r] = (row0 + mt * 32 + 4 * h + rr) < R2 ? lo + rr * ts : 0x7ffffff0;   // out of range: load 0 / store dropped
     }
     float v[16], rv[16];
 #pragma unroll
@@ -358,7 +383,7 @@ __global__ void __launch_bounds__(512, 4) cl_respair_f16s(ClPairArgs a) {
       rv[r] = (VSP_DIAG & 8) ? 1.f : __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, off[r], 0, 0));
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-      v[r] = (TERMS == 3 ? hh[nt][r] + cr[nt][r] * (1.f / 2048.f) : hh[nt][r]) + rv[r];
+      v[r] = (TERMS == 3 ? hh[mt][nt][r] + cr[mt][nt][r] * (1.f / 2048.f) : hh[mt][nt][r]) + rv[r];
     if (a.acc_prev && (VSP_DIAG & 8) == 0) {
       float pv[16];
 #pragma unroll
@@ -399,13 +424,13 @@ extern "C" int vsp_debug_stamps(unsigned long long* host, int max_samples, int r
 }
 #endif
 
-template <int NT, int G, int TERMS, bool PF>
+template <int NT, int G, int TERMS, bool PF, int MT>
 static hipError_t launch_pair_tile(ClPairArgs a, int B, hipStream_t s) {
   constexpr int NLc = (RP_BT + RP_HALO + 63) / 64;
   constexpr size_t lds = ((size_t)2 * NLc * 64 * RP_RS + (size_t)4 * G * (RP_CKC / 16) * NT * 512) * sizeof(_Float16);
   static_assert(lds <= 80 * 1024, "two blocks per CU");
   static bool attr_set = false;
-  auto kern = cl_respair_f16s<NT, G, TERMS, PF>;
+  auto kern = cl_respair_f16s<NT, G, TERMS, PF, MT>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
@@ -424,7 +449,7 @@ static hipError_t launch_pair_tile(ClPairArgs a, int B, hipStream_t s) {
   a.tiles = (a.T + R2 - 1) / R2;
   const long n = (long)a.tiles * B;
   if (n <= 0 || n > 0x7fffffffL) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(512), lds, s, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(512 / MT), lds, s, a);
   return hipGetLastError();
 }
 
@@ -436,8 +461,11 @@ hipError_t launch_cl_pair(const ClPairArgs& a, int B, hipStream_t s) {
   if (!cl_pair_supported(a.C, a.K, a.dil) || a.T <= 0 || B <= 0 || (a.x_bs & 3) ||
       (reinterpret_cast<uintptr_t>(a.x) & 15) || a.x == a.out)
     return hipErrorInvalidValue;
-  if (a.terms == 1) return a.C == 32 ? launch_pair_tile<1, 2, 1, true>(a, B, s) : launch_pair_tile<2, 1, 1, true>(a, B, s);
-  return a.C == 32 ? launch_pair_tile<1, 2, 3, true>(a, B, s) : launch_pair_tile<2, 1, 3, false>(a, B, s);
+  static int fat = -1;   // experiment: VSP_PAIR_MT=2 -> 4 fat waves per block
+  if (fat < 0) { const char* e = getenv("VSP_PAIR_MT"); fat = e ? atoi(e) : 1; }
+  if (a.terms == 1) return a.C == 32 ? launch_pair_tile<1, 2, 1, true, 1>(a, B, s) : launch_pair_tile<2, 1, 1, true, 1>(a, B, s);
+  if (fat == 2) return a.C == 32 ? launch_pair_tile<1, 2, 3, true, 2>(a, B, s) : launch_pair_tile<2, 1, 3, true, 2>(a, B, s);
+  return a.C == 32 ? launch_pair_tile<1, 2, 3, true, 1>(a, B, s) : launch_pair_tile<2, 1, 3, false, 1>(a, B, s);
 }
 
 }  // namespace vsp
