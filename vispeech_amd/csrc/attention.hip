@@ -15,16 +15,18 @@
 // The 2w+1 band probabilities go to a small LDS table and are applied to Ev at the end.
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace vsp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int ATT_QB = 128;   // queries per block
 constexpr int ATT_KT = 32;    // keys per tile
 constexpr int ATT_RS = 17;    // row stride of the relative tables (2w+1 <= 16)
 
-template <int DK>
-__global__ void __launch_bounds__(256) attn_relpos_f32(const float* __restrict__ qkv, long bs, long cs,
+// NW = waves (32 queries each) per block: 4; 2 is kept as an experiment switch.
+template <int DK, int NW>
+__global__ void __launch_bounds__(64 * NW) attn_relpos_f32(const float* __restrict__ qkv, long bs, long cs,
                                                        const float* __restrict__ emb_k,
                                                        const float* __restrict__ emb_v,
                                                        const int64_t* __restrict__ lengths,
@@ -32,6 +34,7 @@ __global__ void __launch_bounds__(256) attn_relpos_f32(const float* __restrict__
                                                        int T, int w) {
   constexpr int KS = DK / 2;   // k-steps of the QK^T product
   constexpr int DT = DK / 32;  // 32-row tiles of the head dimension
+  constexpr int ATT_QB = 32 * NW, NTHR = 64 * NW;
   __shared__ __attribute__((aligned(16))) float Ks[DK * ATT_KT];
   __shared__ __attribute__((aligned(16))) float Vs[DK * (ATT_KT + 1)];
   __shared__ float Rl[ATT_QB * ATT_RS];
@@ -56,7 +59,7 @@ __global__ void __launch_bounds__(256) attn_relpos_f32(const float* __restrict__
   for (int s = 0; s < KS; ++s) qf[s] = i < T ? qrow[(size_t)(2 * s + h) * cs + i] / scale : 0.f;
 
   // relative-key logits of the block's queries and the Ev table
-  for (int idx = tid; idx < ATT_QB * nrel; idx += 256) {
+  for (int idx = tid; idx < ATT_QB * nrel; idx += NTHR) {
     const int iq = idx % ATT_QB, r = idx / ATT_QB;
     float sum = 0.f;
     if (i0 + iq < T) {
@@ -64,18 +67,38 @@ __global__ void __launch_bounds__(256) attn_relpos_f32(const float* __restrict__
     }
     Rl[iq * ATT_RS + r] = sum;
   }
-  for (int idx = tid; idx < ATT_QB * ATT_RS; idx += 256) Pb[idx] = 0.f;
-  for (int idx = tid; idx < nrel * DK; idx += 256) Evs[idx] = emb_v[idx];
+  for (int idx = tid; idx < ATT_QB * ATT_RS; idx += NTHR) Pb[idx] = 0.f;
+  for (int idx = tid; idx < nrel * DK; idx += NTHR) Evs[idx] = emb_v[idx];
 
   const int iql = wave * 32 + l31;  // query index local to the block
   const int ntiles = (T + ATT_KT - 1) / ATT_KT;
   float m_run = -3.0e38f, l_run = 0.f;
 
-  auto stage = [&](int j0, bool with_v) {
-    for (int idx = tid; idx < DK * ATT_KT; idx += 256) {
+  // K/V tile staging, split in two so that the loads of tile jt+1 are in flight while tile jt is being
+  // multiplied: fetch() -> registers (coalesced along time), commit() -> LDS after the barrier that
+  // retires the readers of the previous tile.
+  constexpr int NST = (DK * ATT_KT + NTHR - 1) / NTHR;
+  float kreg[NST];
+  [[maybe_unused]] float vreg[NST];
+  auto fetch = [&](int j0, bool with_v) {
+#pragma unroll
+    for (int u = 0; u < NST; ++u) {
+      const int idx = tid + u * NTHR;
       const int d = idx / ATT_KT, jl = idx % ATT_KT, j = j0 + jl;
-      Ks[idx] = j < T ? krow[(size_t)d * cs + j] : 0.f;
-      if (with_v) Vs[d * (ATT_KT + 1) + jl] = j < T ? vrow[(size_t)d * cs + j] : 0.f;
+      const bool ok = idx < DK * ATT_KT && j < T;
+      kreg[u] = ok ? krow[(size_t)d * cs + j] : 0.f;
+      if (with_v) vreg[u] = ok ? vrow[(size_t)d * cs + j] : 0.f;
+    }
+  };
+  auto commit = [&](bool with_v) {
+#pragma unroll
+    for (int u = 0; u < NST; ++u) {
+      const int idx = tid + u * NTHR;
+      if (idx < DK * ATT_KT) {
+        const int d = idx / ATT_KT, jl = idx % ATT_KT;
+        Ks[idx] = kreg[u];
+        if (with_v) Vs[d * (ATT_KT + 1) + jl] = vreg[u];
+      }
     }
   };
   auto scores = [&](int j0, f32x16& acc) {
@@ -97,10 +120,12 @@ __global__ void __launch_bounds__(256) attn_relpos_f32(const float* __restrict__
   };
 
   // ---- pass 1: row statistics
+  fetch(0, false);
   for (int jt = 0; jt < ntiles; ++jt) {
     __syncthreads();
-    stage(jt * ATT_KT, false);
+    commit(false);
     __syncthreads();
+    if (jt + 1 < ntiles) fetch((jt + 1) * ATT_KT, false);
     f32x16 sT;
     scores(jt * ATT_KT, sT);
     float tmax = sT[0];
@@ -122,10 +147,12 @@ __global__ void __launch_bounds__(256) attn_relpos_f32(const float* __restrict__
   for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  fetch(0, true);
   for (int jt = 0; jt < ntiles; ++jt) {
     __syncthreads();
-    stage(jt * ATT_KT, true);
+    commit(true);
     __syncthreads();
+    if (jt + 1 < ntiles) fetch((jt + 1) * ATT_KT, true);
     f32x16 p;
     scores(jt * ATT_KT, p);
 #pragma unroll
@@ -164,24 +191,33 @@ __global__ void __launch_bounds__(256) attn_relpos_f32(const float* __restrict__
   }
 }
 
+template <int DK, int NW>
+static void launch_attn(const float* qkv, long qkv_bs, long qkv_cs, const float* emb_k, const float* emb_v,
+                        const int64_t* lengths, float* out, long o_bs, long o_cs, int B, int H, int n_heads, int T,
+                        int window, hipStream_t s) {
+  dim3 grid((T + 32 * NW - 1) / (32 * NW), n_heads, B);
+  hipLaunchKernelGGL((attn_relpos_f32<DK, NW>), grid, dim3(64 * NW), 0, s, qkv, qkv_bs, qkv_cs, emb_k, emb_v, lengths,
+                     out, o_bs, o_cs, H, T, window);
+}
+
 hipError_t launch_attention(const float* qkv, long qkv_bs, long qkv_cs, const float* emb_k, const float* emb_v,
                             const int64_t* lengths, float* out, long o_bs, long o_cs, int B, int H,
                             int n_heads, int T, int window, hipStream_t s) {
   if (n_heads <= 0 || H % n_heads != 0 || 2 * window + 1 > 16 || T <= 0) return hipErrorInvalidValue;
   const int dk = H / n_heads;
-  dim3 grid((T + ATT_QB - 1) / ATT_QB, n_heads, B);
-  if (dk == 96) {
-    hipLaunchKernelGGL(attn_relpos_f32<96>, grid, dim3(256), 0, s, qkv, qkv_bs, qkv_cs, emb_k, emb_v, lengths,
-                       out, o_bs, o_cs, H, T, window);
-  } else if (dk == 64) {
-    hipLaunchKernelGGL(attn_relpos_f32<64>, grid, dim3(256), 0, s, qkv, qkv_bs, qkv_cs, emb_k, emb_v, lengths,
-                       out, o_bs, o_cs, H, T, window);
-  } else if (dk == 32) {
-    hipLaunchKernelGGL(attn_relpos_f32<32>, grid, dim3(256), 0, s, qkv, qkv_bs, qkv_cs, emb_k, emb_v, lengths,
-                       out, o_bs, o_cs, H, T, window);
-  } else {
-    return hipErrorInvalidValue;
-  }
+  // 128-query blocks; 64-query blocks (VSP_ATT_NW=2, experiment) were measured equal-to-slower even when the
+  // 128-query grid leaves CUs idle (C5: 35.8 vs 35.1 ms per step): each block re-stages every K/V tile
+  static int nw_env = -1;
+  if (nw_env < 0) { const char* e = getenv("VSP_ATT_NW"); nw_env = e ? atoi(e) : 0; }
+  const int nw = nw_env == 2 ? 2 : 4;
+#define VSP_ATT(DKV)                                                                                             \
+  if (nw == 2) launch_attn<DKV, 2>(qkv, qkv_bs, qkv_cs, emb_k, emb_v, lengths, out, o_bs, o_cs, B, H, n_heads, T, window, s); \
+  else launch_attn<DKV, 4>(qkv, qkv_bs, qkv_cs, emb_k, emb_v, lengths, out, o_bs, o_cs, B, H, n_heads, T, window, s)
+  if (dk == 96) { VSP_ATT(96); }
+  else if (dk == 64) { VSP_ATT(64); }
+  else if (dk == 32) { VSP_ATT(32); }
+  else return hipErrorInvalidValue;
+#undef VSP_ATT
   return hipGetLastError();
 }
 
