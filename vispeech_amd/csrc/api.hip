@@ -71,6 +71,7 @@ struct Run {
     a.nchunks = (L.Cin + CONV_CK - 1) / CONV_CK;
     a.alpha = 1.f; a.div = 1.f;
     a.ups_s = L.ups_s; a.ups_p = L.ups_p;
+    a.f16s = L.f16s ? 1 : 0;
     return a;
   }
   void conv(const ConvArgs& a, int B, bool profile = false) {
@@ -504,6 +505,7 @@ int vsp_create(const vsp_config* cfg, int device, vsp_ctx** out) {
   if (!ctx) return VSP_ERR_ARG;
   ctx->cfg = *cfg;
   ctx->device = device;
+  if (const char* e = getenv("VSP_FRAME")) ctx->frame_f16s = strcmp(e, "f32") != 0;
   build_schema(ctx->cfg, ctx->schema);
   const int rc = plan_model(ctx);
   if (const char* e = getenv("VSP_GENERATOR")) {

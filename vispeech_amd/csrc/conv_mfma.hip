@@ -48,7 +48,40 @@ void pack_conv_weights(float* dst, int M, int Cin, int K, const float* dense) {
   }
 }
 
-template <int MT, int NT, int WM, int WN>
+// Split-f16 variant of the same packing (F16S kernels below): the 4 KiB block of one (m-tile, chunk,
+// tap) holds [k-step 0..1][hi, lo][lane][8 halfs]; lane l = row (l & 31), k = 16*ks + 8*(l >> 5) + j.
+// w = wh + wl * 2^-11 exactly as in conv_f16s.hip.
+void pack_conv_weights_f16s(float* dst_f, int M, int Cin, int K, const float* dense) {
+  const int nc = (Cin + CONV_CK - 1) / CONV_CK;
+  std::memset(dst_f, 0, packed_conv_floats(M, Cin, K) * sizeof(float));
+  uint16_t* dst = reinterpret_cast<uint16_t*>(dst_f);
+  for (int row = 0; row < M; ++row) {
+    const int mtile = row >> 5, rin = row & 31;
+    for (int ci = 0; ci < Cin; ++ci) {
+      const int chunk = ci / CONV_CK, cc = ci % CONV_CK;
+      const int ks = cc >> 4, hh = (cc >> 3) & 1, j = cc & 7, lane = rin + 32 * hh;
+      for (int tap = 0; tap < K; ++tap) {
+        const float w = dense[((size_t)row * Cin + ci) * K + tap];
+        const _Float16 h = (_Float16)w;
+        const _Float16 l = (_Float16)((w - (float)h) * 2048.f);
+        const size_t blk = (((size_t)mtile * nc + chunk) * K + tap) * 2048;   // halfs per 4 KiB block
+        std::memcpy(dst + blk + ((size_t)(ks * 2 + 0) * 64 + lane) * 8 + j, &h, 2);
+        std::memcpy(dst + blk + ((size_t)(ks * 2 + 1) * 64 + lane) * 8 + j, &l, 2);
+      }
+    }
+  }
+}
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// F16S: the same implicit GEMM on v_mfma_f32_32x32x16_f16 with fp32-accurate split operands (three
+// MFMAs per product into an HH and a CROSS accumulator, conv_f16s.hip) -- 16/3 x the f32 matrix rate.
+// The staged window is then kept as f16 PAIRS of adjacent input channels, P[ci/2][t] (hi image, lo
+// image; time contiguous, same bytes as the f32 window): a B fragment (8 consecutive ci of one time
+// column) is four conflict-free ds_read_b32, and staging stays a 16-byte ds_write per four columns.
+template <int MT, int NT, int WM, int WN, bool F16S>
 __global__ void __launch_bounds__(64 * WM * WN) conv1d_f32_mfma(ConvArgs a) {
   constexpr int BN = 32 * NT * WN;
   constexpr int LWP = BN + CONV_HALO;
@@ -70,12 +103,25 @@ __global__ void __launch_bounds__(64 * WM * WN) conv1d_f32_mfma(ConvArgs a) {
   const int total_it = a.nchunks * a.K;
 
   f32x16 acc[MT][NT];
+  [[maybe_unused]] f32x16 crs[MT][NT];          // F16S: CROSS accumulator (acc is HH)
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+      for (int r = 0; r < 16; ++r) {
+        acc[mt][nt][r] = 0.f;
+        if constexpr (F16S) crs[mt][nt][r] = 0.f;
+      }
+  unsigned* const ph = reinterpret_cast<unsigned*>(xs);          // F16S: hi image [16][LWP] words
+  unsigned* const pl = ph + (CONV_CK / 2) * LWP;                 //       lo image
+  auto split_pair = [&](float x0, float x1, unsigned& whi, unsigned& wlo) {
+    const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+    const f16x2 hi = {h0, h1};
+    const f16x2 lo = {(_Float16)((x0 - (float)h0) * 2048.f), (_Float16)((x1 - (float)h1) * 2048.f)};
+    whi = __builtin_bit_cast(unsigned, hi);
+    wlo = __builtin_bit_cast(unsigned, lo);
+  };
 
   const float4* wp4 = reinterpret_cast<const float4*>(a.wp);
   float4 a_cur[MT][KG], a_nxt[MT][KG];
@@ -106,7 +152,59 @@ __global__ void __launch_bounds__(64 * WM * WN) conv1d_f32_mfma(ConvArgs a) {
   int it = 0;
   for (int chunk = 0; chunk < a.nchunks; ++chunk) {
     // ---- stage x[chunk] -> LDS with the prologue applied
-    if (vec) {
+    if (vec && F16S) {
+      // pairs of adjacent input channels: two 16-byte loads -> one 16-byte LDS store per image
+      constexpr int RWP = (CONV_CK / 2) / NW;
+      for (int q0 = 0; q0 < LW4; q0 += 64) {
+        const int q4 = q0 + lane;
+        const int t4 = t_start + 4 * q4;
+        const bool tin = q4 < LW4 && t4 >= 0 && t4 < a.T_in;
+        float4 va[RWP], vb[RWP];
+#pragma unroll
+        for (int j = 0; j < RWP; ++j) {
+          const int ci = chunk * CONV_CK + 2 * (wave + j * NW);
+          va[j] = vb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (tin && ci < a.Cin) va[j] = *reinterpret_cast<const float4*>(xb + (size_t)ci * a.x_cs + t4);
+          if (tin && ci + 1 < a.Cin) vb[j] = *reinterpret_cast<const float4*>(xb + (size_t)(ci + 1) * a.x_cs + t4);
+        }
+        if (q4 < LW4) {
+          const int lim = a.in_mask ? (len < a.T_in ? len : a.T_in) : a.T_in;
+#pragma unroll
+          for (int j = 0; j < RWP; ++j) {
+            float ea[4] = {va[j].x, va[j].y, va[j].z, va[j].w}, eb[4] = {vb[j].x, vb[j].y, vb[j].z, vb[j].w};
+            unsigned wh4[4], wl4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              float x0 = (t4 + u < lim) ? ea[u] : 0.f, x1 = (t4 + u < lim) ? eb[u] : 0.f;
+              if (a.in_act) { x0 = x0 > 0.f ? x0 : x0 * a.in_slope; x1 = x1 > 0.f ? x1 : x1 * a.in_slope; }
+              split_pair(x0, x1, wh4[u], wl4[u]);
+            }
+            const int o = (wave + j * NW) * LWP + 4 * q4;
+            *reinterpret_cast<u32x4*>(ph + o) = u32x4{wh4[0], wh4[1], wh4[2], wh4[3]};
+            *reinterpret_cast<u32x4*>(pl + o) = u32x4{wl4[0], wl4[1], wl4[2], wl4[3]};
+          }
+        }
+      }
+    } else if (F16S) {
+      for (int cp = wave; cp < CONV_CK / 2; cp += NW) {
+        const int ci = chunk * CONV_CK + 2 * cp;
+        const float* xr0 = xb + (size_t)ci * a.x_cs;
+        const float* xr1 = xr0 + a.x_cs;
+        for (int col = lane; col < LW; col += 64) {
+          const int t = t0 - a.pad + col;
+          float x0 = 0.f, x1 = 0.f;
+          if (t >= 0 && t < a.T_in && !(a.in_mask && t >= len)) {
+            if (ci < a.Cin) x0 = xr0[t];
+            if (ci + 1 < a.Cin) x1 = xr1[t];
+            if (a.in_act) { x0 = x0 > 0.f ? x0 : x0 * a.in_slope; x1 = x1 > 0.f ? x1 : x1 * a.in_slope; }
+          }
+          unsigned wh1, wl1;
+          split_pair(x0, x1, wh1, wl1);
+          ph[cp * LWP + col] = wh1;
+          pl[cp * LWP + col] = wl1;
+        }
+      }
+    } else if (vec) {
       // 16-byte loads, one row per (wave, j) and all RW rows of a column block in flight at once;
       // the staged window starts at t_start = floor4(t0 - pad) so every load is 16-byte aligned.
       constexpr int RW = CONV_CK / NW;
@@ -157,9 +255,35 @@ __global__ void __launch_bounds__(64 * WM * WN) conv1d_f32_mfma(ConvArgs a) {
     __syncthreads();
     for (int tap = 0; tap < a.K; ++tap, ++it) {
       if (it + 1 < total_it) load_a(it + 1, a_nxt);
+      if constexpr (F16S) {
+        // column of this lane in the pair images, rows 8*ks + 4*h + i
+        const int col = wn * (NT * 32) + l31 + off + tap * a.dil;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          f16x8 bh[NT], bl[NT];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const unsigned* p = ph + (8 * ks + 4 * h) * LWP + col + nt * 32;
+            const unsigned* q = pl + (8 * ks + 4 * h) * LWP + col + nt * 32;
+            bh[nt] = __builtin_bit_cast(f16x8, u32x4{p[0], p[LWP], p[2 * LWP], p[3 * LWP]});
+            bl[nt] = __builtin_bit_cast(f16x8, u32x4{q[0], q[LWP], q[2 * LWP], q[3 * LWP]});
+          }
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const f16x8 ah = __builtin_bit_cast(f16x8, a_cur[mt][2 * ks]);
+            const f16x8 al = __builtin_bit_cast(f16x8, a_cur[mt][2 * ks + 1]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) crs[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[nt], crs[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) crs[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[nt], crs[mt][nt], 0, 0, 0);
+          }
+        }
+      }
       const float* xt = xsb + tap * a.dil;
 #pragma unroll
-      for (int kg = 0; kg < KG; ++kg) {
+      for (int kg = 0; kg < (F16S ? 0 : KG); ++kg) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int kk = kg * 4 + i;
@@ -184,6 +308,14 @@ __global__ void __launch_bounds__(64 * WM * WN) conv1d_f32_mfma(ConvArgs a) {
     __syncthreads();
   }
 
+  if constexpr (F16S) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][nt][r] += crs[mt][nt][r] * (1.f / 2048.f);
+  }
   // ---- epilogue
   const float* resb = a.res ? a.res + (size_t)b * a.r_bs : nullptr;
   float* outb = a.out + (size_t)b * a.o_bs;
@@ -266,12 +398,12 @@ __global__ void __launch_bounds__(64 * WM * WN) conv1d_f32_mfma(ConvArgs a) {
   }
 }
 
-template <int MT, int NT, int WM, int WN>
+template <int MT, int NT, int WM, int WN, bool F16S = false>
 static hipError_t launch_tile(const ConvArgs& a, int B, hipStream_t s) {
   constexpr int BN = 32 * NT * WN, BM = 32 * MT * WM;
   constexpr size_t lds = (size_t)CONV_CK * (BN + CONV_HALO) * sizeof(float);
   static bool attr_set = false;
-  auto kern = conv1d_f32_mfma<MT, NT, WM, WN>;
+  auto kern = conv1d_f32_mfma<MT, NT, WM, WN, F16S>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -286,6 +418,20 @@ static hipError_t launch_tile(const ConvArgs& a, int B, hipStream_t s) {
 hipError_t launch_conv(const ConvArgs& a, int B, hipStream_t s) {
   if ((a.K - 1) * a.dil + 3 > CONV_HALO || a.K < 1 || a.Nq <= 0 || B <= 0) return hipErrorInvalidValue;
   const bool gate = a.act == 2;
+  if (a.f16s) {
+    // split-f16 path: two accumulators per tile, so at most MT*NT = 4 tiles per wave
+    if (a.ups_s > 0) return hipErrorInvalidValue;
+    if (a.M <= 32 && !gate) {
+      if (a.Nq >= 1024) return launch_tile<1, 4, 1, 4, true>(a, B, s);
+      return launch_tile<1, 1, 1, 2, true>(a, B, s);
+    }
+    if (a.Nq <= 96) return launch_tile<2, 1, 1, 2, true>(a, B, s);
+    if (a.M <= 64 || (a.M % 128 != 0 && a.M < 256)) {
+      if (a.Nq >= 1024) return launch_tile<2, 2, 1, 4, true>(a, B, s);
+      return launch_tile<2, 1, 1, 4, true>(a, B, s);
+    }
+    return launch_tile<2, 2, 2, 2, true>(a, B, s);
+  }
   if (a.M <= 32 && !gate) {
     if (a.Nq >= 1024) return launch_tile<1, 4, 1, 4>(a, B, s);
     return launch_tile<1, 1, 1, 2>(a, B, s);

@@ -35,6 +35,7 @@ struct ConvArgs {
   float div;                  // v /= div
   int mask_post;
   int ups_s, ups_p, T_store;  // transposed-conv store: row=(co,r), n = s*q + r - p in [0,T_store)
+  int f16s;                   // weights packed by pack_conv_weights_f16s: split-f16 MFMA path
 };
 
 // the tile shape is chosen from M and Nq
@@ -42,6 +43,7 @@ hipError_t launch_conv(const ConvArgs& a, int B, hipStream_t s);
 size_t packed_conv_floats(int M, int Cin, int K);
 // W(row, ci, tap) accessor -> packed buffer (host).  dst has packed_conv_floats(M,Cin,K) floats.
 void pack_conv_weights(float* dst, int M, int Cin, int K, const float* dense /* [M][Cin][K] */);
+void pack_conv_weights_f16s(float* dst, int M, int Cin, int K, const float* dense /* [M][Cin][K] */);
 
 // ------------------------------------------------------------------------------------------
 // channels-last split-f16 vocoder conv (conv_f16s.hip): x [B][T][Cin], out [B][T][Cout]

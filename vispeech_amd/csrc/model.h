@@ -25,6 +25,7 @@ struct Conv {
   int ups_s = 0, ups_p = 0;
   size_t w = 0;
   long b = -1;
+  bool f16s = false;   // packed for the split-f16 MFMA path of conv_mfma.hip (same bytes as the f32 packing)
 };
 
 // One channels-last split-f16 conv (conv_f16s.hip); wh / wl offsets in floats (2 halfs per float).
@@ -104,6 +105,7 @@ struct vsp_ctx {
   bool ready = false;
   int gen_mode = 1;  // 0: f32 MFMA channel-major generator, 1: split-f16 (fp32-accurate) channels-last generator,
                      // 2: same kernels with plain f16 operands (VSP_GENERATOR=f16, opt-in reduced precision)
+  bool frame_f16s = true;  // frame/phoneme-rate convs on the split-f16 matrix path (VSP_FRAME=f32: f32 MFMA)
   bool fuse_pairs = true;  // ResBlock conv pairs of the 32/64-channel stages as one launch (VSP_FUSE_PAIRS=0: two launches)
   double chunk_mb = 0.0;   // generator batch chunk in MiB per activation tensor (VSP_CHUNK_MB; 0 = whole batch: measured faster)
   // profiling of the dominant kernel

@@ -163,6 +163,7 @@ void build_schema(const vsp_config& c, std::map<std::string, SchemaEntry>& s) {
 // ------------------------------------------------------------------------------------------
 struct Planner {
   size_t cur = 0;
+  bool f16s = false;   // packing of the convs planned from here on
   size_t raw(size_t n) {
     const size_t o = cur;
     cur += (n + 63) / 64 * 64;  // 256-byte granules
@@ -173,6 +174,7 @@ struct Planner {
     c.M = M; c.Cin = Cin; c.K = K; c.dil = dil; c.pad = pad;
     c.w = raw(packed_conv_floats(M, Cin, K));
     c.b = bias ? (long)raw((size_t)M) : -1;
+    c.f16s = f16s;
     return c;
   }
   ClConv clconv(int Cout, int Cin, int K, int dil, int pad, int phases, int ups_p) {
@@ -222,6 +224,7 @@ int plan_model(vsp_ctx* ctx) {
       c.n_resblock_kernels > VSP_MAX_LIST || c.n_resblock_dilations < 1 || c.n_resblock_dilations > VSP_MAX_LIST)
     return ctx->fail(VSP_ERR_ARG, "list sizes out of range");
   Planner p;
+  p.f16s = ctx->frame_f16s;   // everything up to the generator: encoders, predictors, projection, flows, posterior
   m.emb_sym = p.raw((size_t)c.n_vocab * h);
   m.emb_g = p.raw((size_t)c.n_speakers * gin);
   plan_encoder(p, m.enc[0], "enc_p.encoder", c.n_layers, c);
@@ -277,7 +280,8 @@ int plan_model(vsp_ctx* ctx) {
     Q.proj_m = p.conv(inter, h, 1, 1, 0, true);
     Q.proj_s = p.conv(inter, h, 1, 1, 0, true);
   }
-  // generator
+  // generator (its channel-major f32 form is the second implementation kept for VSP_GENERATOR=f32)
+  p.f16s = false;
   const int c0 = c.upsample_initial_channel;
   m.g_pre = p.conv(c0, inter, 7, 1, 3, true);
   m.g_cond = p.conv(c0, gin, 1, 1, 0, true);
@@ -376,7 +380,8 @@ struct Filler {
     for (int r = 0; r < c.M; ++r)
       for (int ci = 0; ci < c.Cin; ++ci)
         for (int t = 0; t < c.K; ++t) dense[((size_t)r * c.Cin + ci) * c.K + t] = w(r, ci, t);
-    pack_conv_weights(arena.data() + c.w, c.M, c.Cin, c.K, dense.data());
+    if (c.f16s) pack_conv_weights_f16s(arena.data() + c.w, c.M, c.Cin, c.K, dense.data());
+    else pack_conv_weights(arena.data() + c.w, c.M, c.Cin, c.K, dense.data());
     if (c.b >= 0)
       for (int r = 0; r < c.M; ++r) arena[c.b + r] = b(r);
   }
