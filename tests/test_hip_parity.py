@@ -405,3 +405,21 @@ def test_fused_resblock_pairs_are_bit_identical_to_two_launches(net, dims, weigh
         a = net._engine.generator(z, g)
         b = two._engine.generator(z, g)
         assert torch.equal(a, b), (B, T, float((a - b).abs().max()))
+
+
+def test_alternative_kernel_paths_match_golden(dims, weights, golden_dir, monkeypatch):
+    """Switchable second implementations stay correct: frame-rate convs on the f32 matrix core
+    (VSP_FRAME=f32) and attention with the key range split inside the block for every launch
+    (VSP_ATT_KSPLIT=1; normally only long single utterances take that path)."""
+    monkeypatch.setenv("VSP_FRAME", "f32")
+    monkeypatch.setenv("VSP_ATT_KSPLIT", "1")
+    from vispeech_amd import config as vcfg
+    from vispeech_amd.models import SynthesizerTrn
+    args, kwargs = vcfg.synthesizer_args(vcfg.default_hparams())
+    m = SynthesizerTrn(*args, **kwargs).eval()
+    m.load_state_dict(weights, strict=True)
+    for case in ("ragged_predictors", "c1_filelist"):
+        g = golden(golden_dir, case)
+        out = run_case(m, g)
+        assert rel_err(to_np(out[0]), g["o"]) <= WAVE_TOL, case
+        assert rel_err(to_np(out[2][2]), g["m_p"]) <= STAGE_TOL, case

@@ -24,8 +24,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int ATT_KT = 32;    // keys per tile
 constexpr int ATT_RS = 17;    // row stride of the relative tables (2w+1 <= 16)
 
-// NW = waves (32 queries each) per block: 4; 2 is kept as an experiment switch.
-template <int DK, int NW>
+// NW waves per block.  KSPLIT = false: each wave owns 32 queries (128-query blocks) and walks every key tile.
+// KSPLIT = true (long single utterances, where 128-query blocks would leave most CUs idle): the block
+// owns 32 queries, every staging step brings NW key tiles and wave w multiplies tile w, so the key range is
+// split NW ways inside the block; row statistics are merged through LDS after pass 1 and the partial O^T
+// tiles are summed through LDS at the end -- NW x the blocks for the same MFMA work.
+template <int DK, int NW, bool KSPLIT>
 __global__ void __launch_bounds__(64 * NW) attn_relpos_f32(const float* __restrict__ qkv, long bs, long cs,
                                                        const float* __restrict__ emb_k,
                                                        const float* __restrict__ emb_v,
@@ -34,9 +38,11 @@ __global__ void __launch_bounds__(64 * NW) attn_relpos_f32(const float* __restri
                                                        int T, int w) {
   constexpr int KS = DK / 2;   // k-steps of the QK^T product
   constexpr int DT = DK / 32;  // 32-row tiles of the head dimension
-  constexpr int ATT_QB = 32 * NW, NTHR = 64 * NW;
-  __shared__ __attribute__((aligned(16))) float Ks[DK * ATT_KT];
-  __shared__ __attribute__((aligned(16))) float Vs[DK * (ATT_KT + 1)];
+  constexpr int ATT_QB = KSPLIT ? 32 : 32 * NW, NTHR = 64 * NW;
+  constexpr int KTA = KSPLIT ? ATT_KT * NW : ATT_KT;     // keys staged per step
+  __shared__ __attribute__((aligned(16))) float KV[DK * KTA + DK * (KTA + 1)];
+  float* const Ks = KV;
+  float* const Vs = KV + DK * KTA;
   __shared__ float Rl[ATT_QB * ATT_RS];
   __shared__ float Pb[ATT_QB * ATT_RS];
   __shared__ float Evs[16 * DK];
@@ -50,7 +56,9 @@ __global__ void __launch_bounds__(64 * NW) attn_relpos_f32(const float* __restri
   const float* krow = qrow + (size_t)H * cs;
   const float* vrow = qrow + (size_t)(2 * H) * cs;
   const float scale = sqrtf((float)DK);
-  const int i = i0 + wave * 32 + l31;  // this lane's query
+  const int qoff = KSPLIT ? 0 : wave * 32;   // first query of this wave inside the block
+  const int koff = KSPLIT ? wave * 32 : 0;   // this wave's key tile inside the staged keys
+  const int i = i0 + qoff + l31;  // this lane's query
 
   // Q fragments (B operand: lane holds q[d = 2s + h][i]) scaled as the reference does
   // (query / sqrt(k_channels), attentions.py:155)
@@ -70,22 +78,22 @@ __global__ void __launch_bounds__(64 * NW) attn_relpos_f32(const float* __restri
   for (int idx = tid; idx < ATT_QB * ATT_RS; idx += NTHR) Pb[idx] = 0.f;
   for (int idx = tid; idx < nrel * DK; idx += NTHR) Evs[idx] = emb_v[idx];
 
-  const int iql = wave * 32 + l31;  // query index local to the block
-  const int ntiles = (T + ATT_KT - 1) / ATT_KT;
+  const int iql = qoff + l31;  // query index local to the block
+  const int ntiles = (T + KTA - 1) / KTA;
   float m_run = -3.0e38f, l_run = 0.f;
 
   // K/V tile staging, split in two so that the loads of tile jt+1 are in flight while tile jt is being
   // multiplied: fetch() -> registers (coalesced along time), commit() -> LDS after the barrier that
   // retires the readers of the previous tile.
-  constexpr int NST = (DK * ATT_KT + NTHR - 1) / NTHR;
+  constexpr int NST = (DK * KTA + NTHR - 1) / NTHR;
   float kreg[NST];
   [[maybe_unused]] float vreg[NST];
   auto fetch = [&](int j0, bool with_v) {
 #pragma unroll
     for (int u = 0; u < NST; ++u) {
       const int idx = tid + u * NTHR;
-      const int d = idx / ATT_KT, jl = idx % ATT_KT, j = j0 + jl;
-      const bool ok = idx < DK * ATT_KT && j < T;
+      const int d = idx / KTA, jl = idx % KTA, j = j0 + jl;
+      const bool ok = idx < DK * KTA && j < T;
       kreg[u] = ok ? krow[(size_t)d * cs + j] : 0.f;
       if (with_v) vreg[u] = ok ? vrow[(size_t)d * cs + j] : 0.f;
     }
@@ -94,10 +102,10 @@ __global__ void __launch_bounds__(64 * NW) attn_relpos_f32(const float* __restri
 #pragma unroll
     for (int u = 0; u < NST; ++u) {
       const int idx = tid + u * NTHR;
-      if (idx < DK * ATT_KT) {
-        const int d = idx / ATT_KT, jl = idx % ATT_KT;
+      if (idx < DK * KTA) {
+        const int d = idx / KTA, jl = idx % KTA;
         Ks[idx] = kreg[u];
-        if (with_v) Vs[d * (ATT_KT + 1) + jl] = vreg[u];
+        if (with_v) Vs[d * (KTA + 1) + jl] = vreg[u];
       }
     }
   };
@@ -106,7 +114,7 @@ __global__ void __launch_bounds__(64 * NW) attn_relpos_f32(const float* __restri
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
     for (int s = 0; s < KS; ++s)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[(2 * s + h) * ATT_KT + l31], qf[s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[(2 * s + h) * KTA + koff + l31], qf[s], acc, 0, 0, 0);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -125,9 +133,9 @@ __global__ void __launch_bounds__(64 * NW) attn_relpos_f32(const float* __restri
     __syncthreads();
     commit(false);
     __syncthreads();
-    if (jt + 1 < ntiles) fetch((jt + 1) * ATT_KT, false);
+    if (jt + 1 < ntiles) fetch((jt + 1) * KTA, false);
     f32x16 sT;
-    scores(jt * ATT_KT, sT);
+    scores(jt * KTA + koff, sT);
     float tmax = sT[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sT[r]);
@@ -139,7 +147,21 @@ __global__ void __launch_bounds__(64 * NW) attn_relpos_f32(const float* __restri
     l_run = l_run * expf(m_run - m_new) + part;
     m_run = m_new;
   }
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  float l_tot = l_run + __shfl_xor(l_run, 32);
+  if constexpr (KSPLIT) {
+    // merge the NW key ranges: m = max_w m_w, l = sum_w l_w * exp(m_w - m)
+    __shared__ float Mx[NW * 32], Lx[NW * 32];
+    if (h == 0) { Mx[wave * 32 + l31] = m_run; Lx[wave * 32 + l31] = l_tot; }
+    __syncthreads();
+    float mg = Mx[l31];
+#pragma unroll
+    for (int ww = 1; ww < NW; ++ww) mg = fmaxf(mg, Mx[ww * 32 + l31]);
+    float lg = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) lg += Lx[ww * 32 + l31] * expf(Mx[ww * 32 + l31] - mg);
+    m_run = mg;
+    l_tot = lg;
+  }
 
   // ---- pass 2: probabilities and P.V
   f32x16 o[DT];
@@ -152,12 +174,12 @@ __global__ void __launch_bounds__(64 * NW) attn_relpos_f32(const float* __restri
     __syncthreads();
     commit(true);
     __syncthreads();
-    if (jt + 1 < ntiles) fetch((jt + 1) * ATT_KT, true);
+    if (jt + 1 < ntiles) fetch((jt + 1) * KTA, true);
     f32x16 p;
-    scores(jt * ATT_KT, p);
+    scores(jt * KTA + koff, p);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int j = jt * ATT_KT + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int j = jt * KTA + koff + (r & 3) + 8 * (r >> 2) + 4 * h;
       const float pv = expf(p[r] - m_run) / l_tot;
       p[r] = pv;
       const int rel = j - i + w;
@@ -168,10 +190,32 @@ __global__ void __launch_bounds__(64 * NW) attn_relpos_f32(const float* __restri
       const int jl = (r & 3) + 8 * (r >> 2) + 4 * h;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
-        o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[(dt * 32 + l31) * (ATT_KT + 1) + jl], p[r], o[dt], 0, 0, 0);
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[(dt * 32 + l31) * (KTA + 1) + koff + jl], p[r], o[dt], 0, 0, 0);
     }
   }
   __syncthreads();
+  if constexpr (KSPLIT) {
+    // sum the NW partial O^T tiles through LDS (the K/V staging area is free now), add the
+    // relative-value term and store: thread -> (d, query), query fastest = coalesced along time
+    float* const Ored = KV;                       // [NW][DK][32]
+    static_assert(NW * DK * 32 <= DK * KTA + DK * (KTA + 1), "reduction buffer fits the staging area");
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        Ored[(wave * DK + dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = o[dt][r];
+    __syncthreads();
+    for (int idx = tid; idx < DK * 32; idx += NTHR) {
+      const int d = idx >> 5, q = idx & 31;
+      if (i0 + q >= T) continue;
+      float v = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < NW; ++ww) v += Ored[(ww * DK + d) * 32 + q];
+      for (int e = 0; e < nrel; ++e) v += Pb[q * ATT_RS + e] * Evs[e * DK + d];
+      out[(size_t)b * o_bs + (size_t)(hd * DK + d) * o_cs + i0 + q] = v;
+    }
+    return;
+  }
   // ---- relative-value term and store (lane = query -> coalesced along time)
   if (i < T) {
     float pb[16];
@@ -191,13 +235,14 @@ __global__ void __launch_bounds__(64 * NW) attn_relpos_f32(const float* __restri
   }
 }
 
-template <int DK, int NW>
+template <int DK, int NW, bool KSPLIT>
 static void launch_attn(const float* qkv, long qkv_bs, long qkv_cs, const float* emb_k, const float* emb_v,
                         const int64_t* lengths, float* out, long o_bs, long o_cs, int B, int H, int n_heads, int T,
                         int window, hipStream_t s) {
-  dim3 grid((T + 32 * NW - 1) / (32 * NW), n_heads, B);
-  hipLaunchKernelGGL((attn_relpos_f32<DK, NW>), grid, dim3(64 * NW), 0, s, qkv, qkv_bs, qkv_cs, emb_k, emb_v, lengths,
-                     out, o_bs, o_cs, H, T, window);
+  constexpr int QB = KSPLIT ? 32 : 32 * NW;
+  dim3 grid((T + QB - 1) / QB, n_heads, B);
+  hipLaunchKernelGGL((attn_relpos_f32<DK, NW, KSPLIT>), grid, dim3(64 * NW), 0, s, qkv, qkv_bs, qkv_cs, emb_k, emb_v,
+                     lengths, out, o_bs, o_cs, H, T, window);
 }
 
 hipError_t launch_attention(const float* qkv, long qkv_bs, long qkv_cs, const float* emb_k, const float* emb_v,
@@ -205,14 +250,15 @@ hipError_t launch_attention(const float* qkv, long qkv_bs, long qkv_cs, const fl
                             int n_heads, int T, int window, hipStream_t s) {
   if (n_heads <= 0 || H % n_heads != 0 || 2 * window + 1 > 16 || T <= 0) return hipErrorInvalidValue;
   const int dk = H / n_heads;
-  // 128-query blocks; 64-query blocks (VSP_ATT_NW=2, experiment) were measured equal-to-slower even when the
-  // 128-query grid leaves CUs idle (C5: 35.8 vs 35.1 ms per step): each block re-stages every K/V tile
-  static int nw_env = -1;
-  if (nw_env < 0) { const char* e = getenv("VSP_ATT_NW"); nw_env = e ? atoi(e) : 0; }
-  const int nw = nw_env == 2 ? 2 : 4;
+  // 128-query blocks (each wave its own queries) when they fill the chip; otherwise 32-query blocks whose
+  // waves split the keys (VSP_ATT_KSPLIT=0/1 forces one or the other: experiment switch)
+  static int ks_env = -2;
+  if (ks_env == -2) { const char* e = getenv("VSP_ATT_KSPLIT"); ks_env = e ? atoi(e) : -1; }
+  const long blocks = (long)((T + 127) / 128) * n_heads * B;
+  const bool ksplit = ks_env >= 0 ? ks_env != 0 : blocks < 256;
 #define VSP_ATT(DKV)                                                                                             \
-  if (nw == 2) launch_attn<DKV, 2>(qkv, qkv_bs, qkv_cs, emb_k, emb_v, lengths, out, o_bs, o_cs, B, H, n_heads, T, window, s); \
-  else launch_attn<DKV, 4>(qkv, qkv_bs, qkv_cs, emb_k, emb_v, lengths, out, o_bs, o_cs, B, H, n_heads, T, window, s)
+  if (ksplit) launch_attn<DKV, 4, true>(qkv, qkv_bs, qkv_cs, emb_k, emb_v, lengths, out, o_bs, o_cs, B, H, n_heads, T, window, s); \
+  else launch_attn<DKV, 4, false>(qkv, qkv_bs, qkv_cs, emb_k, emb_v, lengths, out, o_bs, o_cs, B, H, n_heads, T, window, s)
   if (dk == 96) { VSP_ATT(96); }
   else if (dk == 64) { VSP_ATT(64); }
   else if (dk == 32) { VSP_ATT(32); }
