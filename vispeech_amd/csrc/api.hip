@@ -203,7 +203,7 @@ void run_encoder(Run& r, const EncoderW& E, int B, int T, T3 x_in, const int64_t
     r.conv(a, B);
     if (!r.dry() && r.ok())
       r.chk(launch_attention(QKV.p, QKV.bs, QKV.cs, r.A(L.ek), r.A(L.ev), lengths, AT.p, AT.bs, AT.cs, B, h,
-                             c.n_heads, T, c.window_size, r.s), "attention");
+                             c.n_heads, T, c.window_size, r.ctx->att_ksplit, r.s), "attention");
     // S = (x*mask for layer 0 | x) + conv_o(att)
     a = r.args(L.o, AT, S, T, T);
     a.res = X.p; a.r_bs = X.bs; a.r_cs = X.cs;
@@ -506,6 +506,7 @@ int vsp_create(const vsp_config* cfg, int device, vsp_ctx** out) {
   ctx->cfg = *cfg;
   ctx->device = device;
   if (const char* e = getenv("VSP_FRAME")) ctx->frame_f16s = strcmp(e, "f32") != 0;
+  if (const char* e = getenv("VSP_ATT_KSPLIT")) ctx->att_ksplit = atoi(e);
   build_schema(ctx->cfg, ctx->schema);
   const int rc = plan_model(ctx);
   if (const char* e = getenv("VSP_GENERATOR")) {

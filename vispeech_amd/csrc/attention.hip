@@ -247,15 +247,13 @@ static void launch_attn(const float* qkv, long qkv_bs, long qkv_cs, const float*
 
 hipError_t launch_attention(const float* qkv, long qkv_bs, long qkv_cs, const float* emb_k, const float* emb_v,
                             const int64_t* lengths, float* out, long o_bs, long o_cs, int B, int H,
-                            int n_heads, int T, int window, hipStream_t s) {
+                            int n_heads, int T, int window, int ksplit_mode, hipStream_t s) {
   if (n_heads <= 0 || H % n_heads != 0 || 2 * window + 1 > 16 || T <= 0) return hipErrorInvalidValue;
   const int dk = H / n_heads;
   // 128-query blocks (each wave its own queries) when they fill the chip; otherwise 32-query blocks whose
-  // waves split the keys (VSP_ATT_KSPLIT=0/1 forces one or the other: experiment switch)
-  static int ks_env = -2;
-  if (ks_env == -2) { const char* e = getenv("VSP_ATT_KSPLIT"); ks_env = e ? atoi(e) : -1; }
+  // waves split the keys (ksplit_mode 0/1 forces one or the other, < 0 = automatic)
   const long blocks = (long)((T + 127) / 128) * n_heads * B;
-  const bool ksplit = ks_env >= 0 ? ks_env != 0 : blocks < 256;
+  const bool ksplit = ksplit_mode >= 0 ? ksplit_mode != 0 : blocks < 256;
 #define VSP_ATT(DKV)                                                                                             \
   if (ksplit) launch_attn<DKV, 4, true>(qkv, qkv_bs, qkv_cs, emb_k, emb_v, lengths, out, o_bs, o_cs, B, H, n_heads, T, window, s); \
   else launch_attn<DKV, 4, false>(qkv, qkv_bs, qkv_cs, emb_k, emb_v, lengths, out, o_bs, o_cs, B, H, n_heads, T, window, s)

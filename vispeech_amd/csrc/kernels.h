@@ -89,7 +89,7 @@ hipError_t launch_conv_post_cl(const float* x, long x_bs, int x_ts, const float*
 // qkv [B][3*H][T]: rows [0,H) = q, [H,2H) = k, [2H,3H) = v; out [B][H][T].
 hipError_t launch_attention(const float* qkv, long qkv_bs, long qkv_cs, const float* emb_k,
                             const float* emb_v, const int64_t* lengths, float* out, long o_bs,
-                            long o_cs, int B, int H, int n_heads, int T, int window, hipStream_t s);
+                            long o_cs, int B, int H, int n_heads, int T, int window, int ksplit_mode, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------
 // small kernels (misc.hip)

@@ -106,6 +106,7 @@ struct vsp_ctx {
   int gen_mode = 1;  // 0: f32 MFMA channel-major generator, 1: split-f16 (fp32-accurate) channels-last generator,
                      // 2: same kernels with plain f16 operands (VSP_GENERATOR=f16, opt-in reduced precision)
   bool frame_f16s = true;  // frame/phoneme-rate convs on the split-f16 matrix path (VSP_FRAME=f32: f32 MFMA)
+  int att_ksplit = -1;     // attention key-split blocks: -1 automatic (under-filled grids), 0 never, 1 always (VSP_ATT_KSPLIT)
   bool fuse_pairs = true;  // ResBlock conv pairs of the 32/64-channel stages as one launch (VSP_FUSE_PAIRS=0: two launches)
   double chunk_mb = 0.0;   // generator batch chunk in MiB per activation tensor (VSP_CHUNK_MB; 0 = whole batch: measured faster)
   // profiling of the dominant kernel
