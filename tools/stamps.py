@@ -29,6 +29,33 @@ g = torch.from_numpy(r.standard_normal((B, dims.gin_channels)).astype(np.float32
 net._engine.generator(z, g)
 torch.cuda.synchronize()
 lib = _lib.lib()
+if os.environ.get("VSP_STAMP_CL") is not None:
+    # cl_conv_f16s (128-column tile): launch index within the first generator call: 0 ups0, 1..18 stage 0
+    # (k3: 1-6, k7: 7-12, k11: 13-18), 19 ups1, 20..37 stage 1.  Stamps: start | staged | barrier |
+    # per step: MFMAs done, next slice written, barrier | epilogue start | end.
+    fn = lib.vsp_debug_stamps_cl
+    fn.restype = C.c_int
+    NS, NSTAMP = 128, 160
+    buf = np.zeros((NS, NSTAMP), dtype=np.uint64)
+    n = fn(buf.ctypes.data_as(C.c_void_p), NS, 1)
+    print(f"cl_conv_f16s launch #{os.environ['VSP_STAMP_CL']}: {n} sampled blocks (wave 0)")
+    s = buf[:n].astype(np.int64)
+    counts = (s > 0).sum(axis=1)
+    for cnt in sorted(set(counts.tolist())):
+        g = s[counts == cnt][:, :cnt]
+        rel = (g - g[:, :1]) / 100.0
+        med = np.median(rel, axis=0)
+        d = np.diff(med)
+        print(f"-- {len(g)} blocks with {cnt} stamps: block lifetime median {med[-1]:.2f} us")
+        body = d[2:-2]
+        k = len(body) // 3 * 3
+        b3 = body[:k].reshape(-1, 3)
+        print(f"   prologue {d[0]:.2f} + barrier {d[1]:.2f}; per step (median over {len(b3)} steps): MFMA phase "
+              f"{np.median(b3[:, 0]):.2f}, slice write {np.median(b3[:, 1]):.2f}, barrier {np.median(b3[:, 2]):.2f}; "
+              f"sum of MFMA phases {b3[:, 0].sum():.1f}, writes {b3[:, 1].sum():.1f}, barriers {b3[:, 2].sum():.1f}; "
+              f"tail {' '.join(f'{x:.2f}' for x in d[-3:])}")
+        print("   deltas us:", " ".join(f"{x:.2f}" for x in d[:40]), "...")
+    sys.exit(0)
 fn = lib.vsp_debug_stamps
 fn.restype = C.c_int
 NS, NSTAMP = 256, 64

@@ -24,6 +24,7 @@
 // resblock averaging).
 #include "kernels.h"
 
+#include <cstdlib>
 #include <cstring>
 
 namespace vsp {
@@ -33,6 +34,22 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CL_HALO = 64;  // max (K-1)*dil
+
+// VSP_STAMPS (diagnostic build, tools/stamps.py): wave 0 of every 61st block of the VSP_STAMP_LAUNCH-th launch
+// records wall-clock stamps (s_memrealtime, 100 MHz) at its phase boundaries; read back by vsp_debug_stamps_cl.
+#ifdef VSP_STAMPS
+constexpr int CL_NSTAMP = 160, CL_NSAMPLE = 128;
+__device__ unsigned long long g_cl_stamps[CL_NSAMPLE][CL_NSTAMP];
+__device__ unsigned g_cl_stamp_count;
+#define CL_STAMP()                                                          \
+  do {                                                                      \
+    if (stamp_slot >= 0 && stamp_n < CL_NSTAMP && lane == 0)                \
+      g_cl_stamps[stamp_slot][stamp_n] = __builtin_amdgcn_s_memrealtime();  \
+    ++stamp_n;                                                              \
+  } while (0)
+#else
+#define CL_STAMP() ((void)0)
+#endif
 
 size_t packed_cl_halfs(int Cout, int Cin, int K, int phases) {
   return (size_t)phases * K * (Cin / 16) * (Cout / 32) * 64 * 8;
@@ -79,7 +96,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // TERMS = 3: fp32-accurate split product (default).  TERMS = 1: plain f16 operands (hi images only,
 // one MFMA per product) -- the opt-in reduced-precision mode VSP_GENERATOR=f16 (BASELINE config 3's
 // low-precision variant), NOT used by bench.py or the parity gates.
-template <int MT, int NT, int WM, int WN, int CKC, int G, bool PF, int WD, int TERMS>
+// GLDS: the weight slices go global -> LDS directly (global_load_lds_dwordx4: one 1 KiB fragment block per
+// wave-instruction, exactly the lane-linear layout of the ring), one slice ahead; no staging registers,
+// no ds_write -- the registers this frees pay for the fragment double-buffer (PF) of the 128-column tile.
+template <int MT, int NT, int WM, int WN, int CKC, int G, bool PF, int WD, int TERMS, bool GLDS = false>
 __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
   constexpr int BT = 32 * MT * WM;
   constexpr int RS = CKC + 8;                 // LDS row stride of the activation images (halfs)
@@ -133,6 +153,16 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
       for (int r = 0; r < 16; ++r) { hh[mt][nt][r] = bias; cr[mt][nt][r] = 0.f; }
   }
 
+#ifdef VSP_STAMPS
+  int stamp_slot = -1, stamp_n = 0;
+  if (wave == ((a.terms >> 12) & 7) && (blockIdx.x + 7 * blockIdx.z) % 61 == 3 && blockIdx.y == 0 && (a.terms & 0x100)) {
+    unsigned sl_ = 0;
+    if (lane == 0) sl_ = atomicAdd(&g_cl_stamp_count, 1u);
+    sl_ = __builtin_amdgcn_readfirstlane(sl_);
+    stamp_slot = sl_ < (unsigned)CL_NSAMPLE ? (int)sl_ : -1;
+  }
+  CL_STAMP();                                   // 0: start
+#endif
   const uint4* WHg = reinterpret_cast<const uint4*>(a.wh);
   const uint4* WLg = reinterpret_cast<const uint4*>(a.wl);
 
@@ -182,7 +212,25 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
   // the kernel WITHOUT its MFMAs still took 70 % of the time); the LDS ring stays at two slots,
   // slice s+1 is written at the end of step s.
   static_assert(WD >= 1 && WD <= 3, "prefetch distance");
+  static_assert(!GLDS || WD == 1, "the LDS-DMA ring runs one slice ahead");
   uint4 wq[WD][NWL];
+  // LDS-DMA variant of w_issue + w_write: slice `step` -> ring slot `buf`
+  auto w_dma = [&](int step, int buf) {
+    const int chunk = step / ns, sl = step - chunk * ns;
+#pragma unroll
+    for (int u = 0; u < NWL; ++u) {
+      const int blk = u * NWV + wave;
+      const int ntl = blk % NTB, ks = (blk / NTB) % KS, g = (blk / (NTB * KS)) % G, img = blk / (NTB * KS * G);
+      const int tap = sl * G + g;
+      if (blk < NBLK && tap < a.K && (VSP_DIAG & 2) == 0) {
+        const size_t src = ((((size_t)ph * a.K + tap) * nks + chunk * KS + ks) * nnt + cb * NTB + ntl) * 64;
+        const uint4* gp = (img == 0 ? WHg : WLg) + src + lane;
+        _Float16* lp = Wb + buf * 2 * WIMG + blk * 512;     // 1 KiB per fragment block, wave-uniform
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                         (__attribute__((address_space(3))) void*)lp, 16, 0, 0);
+      }
+    }
+  };
   auto w_issue = [&](int step, uint4(&wv)[NWL]) {
     const int chunk = step / ns, sl = step - chunk * ns;
 #pragma unroll
@@ -253,13 +301,17 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
   };
 
   x_issue(0);
-  w_issue(0, wq[0]);
+  if constexpr (GLDS) w_dma(0, 0);
+  else w_issue(0, wq[0]);
   x_write();
-  w_write(0, wq[0]);
+  if constexpr (!GLDS) w_write(0, wq[0]);
 #pragma unroll
   for (int d = 1; d < WD; ++d)
     if (d < nsteps) w_issue(d, wq[d % WD]);
+  if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  CL_STAMP();                                   // 1: first window + slice staged
   __syncthreads();
+  CL_STAMP();                                   // 2: barrier
   f16x8 xhA[MT], xlA[MT], whA[NT], wlA[NT];
   [[maybe_unused]] f16x8 xhB[MT], xlB[MT], whB[NT], wlB[NT];
   // one step; `ld` receives slice step+WD, `st` holds slice step+1
@@ -290,13 +342,16 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
         mma(xhA, xlA, whA, wlA);
       }
     }
+    CL_STAMP();                                 // step: MFMAs done
     if (more) {
       if (new_chunk) {
         __syncthreads();          // every wave is done reading the activation window
         x_write();
       }
       w_write((step + 1) & 1, st);  // the other ring slot: last read one barrier ago
+      CL_STAMP();                               // step: next slice (and window) written
       __syncthreads();
+      CL_STAMP();                               // step: barrier
     }
   };
   // slice j lives in register set j % WD: step s loads into set s % WD (freed at the end of step
@@ -308,12 +363,33 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
       const int chunk = step / ns, sl = step - chunk * ns;
       const bool more = step + 1 < nsteps;
       const bool new_chunk = more && sl == ns - 1;
-      if (more) w_issue(step + 1, wq[0]);
+      if (more) {
+        if constexpr (GLDS) w_dma(step + 1, (step + 1) & 1);   // that slot was last read one barrier ago
+        else w_issue(step + 1, wq[0]);
+      }
       if (new_chunk) x_issue(chunk + 1);
       const _Float16* Wc = Wb + (step & 1) * 2 * WIMG;
       const int tap0 = sl * G;
       const int nit = ((a.K - tap0) < G ? (a.K - tap0) : G) * KS;
-      if constexpr (PF) {
+      if constexpr (PF && G == 1 && KS == 4) {
+        // one tap per slice: the four k-steps are a fixed, branch-free schedule (fragments of k-step i+1
+        // requested before the MFMAs of k-step i, so the compiler can count its LDS waits)
+        load_frags(Wc, tap0, 0, xhA, xlA, whA, wlA);
+        load_frags(Wc, tap0, 1, xhB, xlB, whB, wlB);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(xhA, xlA, whA, wlA);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(Wc, tap0, 2, xhA, xlA, whA, wlA);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(xhB, xlB, whB, wlB);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(Wc, tap0, 3, xhB, xlB, whB, wlB);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(xhA, xlA, whA, wlA);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(xhB, xlB, whB, wlB);
+        __builtin_amdgcn_sched_barrier(0);
+      } else if constexpr (PF) {
         load_frags(Wc, tap0, 0, xhA, xlA, whA, wlA);
         for (int it = 0; it < nit; it += 2) {
           if (it + 1 < nit) load_frags(Wc, tap0, it + 1, xhB, xlB, whB, wlB);
@@ -329,13 +405,17 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
           mma(xhA, xlA, whA, wlA);
         }
       }
+      CL_STAMP();                               // step: MFMAs done
       if (more) {
         if (new_chunk) {
           __syncthreads();
           x_write();
         }
-        w_write((step + 1) & 1, wq[0]);
+        if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA'd slice has landed
+        else w_write((step + 1) & 1, wq[0]);
+        CL_STAMP();                             // step: next slice (and window) in LDS
         __syncthreads();
+        CL_STAMP();                             // step: barrier
       }
     }
   } else if constexpr (WD == 2) {
@@ -351,6 +431,7 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
     }
   }
 
+  CL_STAMP();                                   // epilogue start
   // ---- epilogue.  D tile: register r is time row rr(r) = (r&3) + 8*(r>>2) (+4h), lane = channel.
   //      Offsets (bytes, 32-bit) = lane part once per (mt, nt) + wave-uniform row part; rows outside
   //      [0, T_store) fall outside the descriptor: loads give 0, stores are dropped.
@@ -399,10 +480,39 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
       }
     }
   }
+#ifdef VSP_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  CL_STAMP();                                   // end (stores retired)
+#endif
 }
 
-template <int MT, int NT, int WM, int WN, int CKC, int G, bool PF, int WD, int TERMS>
-static hipError_t launch_cl_tile(const ClConvArgs& a, int B, hipStream_t s) {
+#ifdef VSP_STAMPS
+extern "C" int vsp_debug_stamps_cl(unsigned long long* host, int max_samples, int reset) {
+  unsigned n = 0;
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_cl_stamp_count), sizeof n);
+  if ((int)n > max_samples) n = max_samples;
+  if (n > (unsigned)CL_NSAMPLE) n = CL_NSAMPLE;
+  (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_cl_stamps), (size_t)n * CL_NSTAMP * sizeof(unsigned long long));
+  if (reset) { const unsigned z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cl_stamp_count), &z, sizeof z); }
+  return (int)n;
+}
+#endif
+
+template <int MT, int NT, int WM, int WN, int CKC, int G, bool PF, int WD, int TERMS, bool GLDS = false>
+static hipError_t launch_cl_tile(const ClConvArgs& a_in, int B, hipStream_t s) {
+  ClConvArgs a = a_in;
+#ifdef VSP_STAMPS
+  {  // stamps only in the VSP_STAMP_CL-th launch of this tile type (0-based)
+    static int launch_no = 0;
+    static int target = -2;
+    if (target == -2) { const char* e = getenv("VSP_STAMP_CL"); target = e ? atoi(e) : -1; }
+    if (launch_no++ == target) {
+      const char* w = getenv("VSP_STAMP_WAVE");
+      a.terms |= 0x100 | ((w ? atoi(w) : 0) << 12);
+    }
+  }
+#endif
   constexpr int BT = 32 * MT * WM;
   constexpr int RPU = (64 * WM * WN) / (CKC / 4);
   constexpr int WMAXL = (BT + CL_HALO + RPU - 1) / RPU * RPU;
@@ -410,7 +520,7 @@ static hipError_t launch_cl_tile(const ClConvArgs& a, int B, hipStream_t s) {
                          sizeof(_Float16);
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
-  auto kern = cl_conv_f16s<MT, NT, WM, WN, CKC, G, PF, WD, TERMS>;
+  auto kern = cl_conv_f16s<MT, NT, WM, WN, CKC, G, PF, WD, TERMS, GLDS>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -438,7 +548,15 @@ hipError_t launch_cl_conv(const ClConvArgs& a, int B, hipStream_t s) {
     if (a.Cout % 64 == 0) return launch_cl_tile<2, 1, 4, 2, 32, 1, true, 1, 1>(a, B, s);
     return launch_cl_tile<1, 1, 8, 1, 32, 2, true, 1, 1>(a, B, s);
   }
-  if (a.Cout % 128 == 0 && a.Cin % 64 == 0) return launch_cl_tile<2, 2, 4, 2, 64, 1, false, 2, 3>(a, B, s);
+  // 128-column tile: weight ring filled by LDS-DMA, fragments double-buffered on a fixed schedule (default);
+  // VSP_BIG_TILE=0 selects the register-staged ring (two slices ahead, no fragment prefetch), 1 the DMA ring alone
+  static int big = -1;
+  if (big < 0) { const char* e = getenv("VSP_BIG_TILE"); big = e ? atoi(e) : 2; }
+  if (a.Cout % 128 == 0 && a.Cin % 64 == 0) {
+    if (big == 1) return launch_cl_tile<2, 2, 4, 2, 64, 1, false, 1, 3, true>(a, B, s);
+    if (big == 0) return launch_cl_tile<2, 2, 4, 2, 64, 1, false, 2, 3>(a, B, s);
+    return launch_cl_tile<2, 2, 4, 2, 64, 1, true, 1, 3, true>(a, B, s);
+  }
   if (a.Cout % 64 == 0) return launch_cl_tile<2, 1, 4, 2, 32, 1, true, 1, 3>(a, B, s);
   return launch_cl_tile<1, 1, 8, 1, 32, 2, true, 1, 3>(a, B, s);
 }
