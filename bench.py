@@ -103,11 +103,18 @@ def main():
     from vispeech_amd.schema import ModelDims
     from vispeech_amd.synth import WORKLOADS, synth_batch, synth_state_dict
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU; VSP_BENCH_BACKEND=gloo (test hook) lets several ranks share one GPU to exercise the
+    # multi-process path on a single-GPU box -- RCCL itself refuses two ranks on one device
+    backend = os.environ.get("VSP_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     dims = ModelDims()
     hps = vcfg.default_hparams()
