@@ -143,7 +143,28 @@ int vsp_decode(vsp_ctx* ctx, void* stream, int B, int Tp, int Tf, int max_len,
                float* o, uint8_t* x_mask, float* z, float* z_p, float* m_p, float* logs_p,
                void* workspace, int64_t workspace_bytes);
 
+/* One-call form of the path for callers that know an upper bound of the frame count up front (supplied
+ * durations, or a fixed max_len): vsp_encode + vsp_decode with Tf = tf_pad and NO host synchronisation.
+ * tf_pad must be >= every utterance's frame count (frames past it are cut off; frame_lengths is returned
+ * so the caller can check afterwards).  Arguments as in vsp_encode / vsp_decode; workspace >=
+ * vsp_infer_workspace_bytes(ctx, B, Tp, tf_pad). */
+int64_t vsp_infer_workspace_bytes(const vsp_ctx* ctx, int B, int Tp, int tf_pad);
+int vsp_infer(vsp_ctx* ctx, void* stream, int B, int Tp, int tf_pad, int max_len,
+              const int64_t* phonemes, const int64_t* lengths, const int64_t* sid,
+              const float* duration_ctl, const float* pitch_ctl, const float* energy_ctl,
+              float duration_scale, float pitch_scale, float energy_scale,
+              const float* noise, float noise_scale,
+              float* o, uint8_t* x_mask, float* z, float* z_p, float* m_p, float* logs_p,
+              float* duration, float* f0, float* energy, int64_t* frame_lengths,
+              void* workspace, int64_t workspace_bytes);
+
 /* ---- per-stage entry points (unit parity against the oracle) ------------------------------ */
+/* MultiHeadAttention.attention (reference attentions.py:148-179 with the relative-position helpers
+ * :181-243) of layer `layer` of encoder `which` (0 enc_p.encoder, 1 pitch_predictor.pitch_net,
+ * 2 frame_prior_net.fft_block): qkv [B][3H][T] = conv_q | conv_k | conv_v outputs, lengths[B] (attn_mask =
+ * mask x mask), out [B][H][T] = the tensor conv_o consumes.  No workspace. */
+int vsp_attention(vsp_ctx* ctx, void* stream, int which, int layer, int B, int T, const float* qkv,
+                  const int64_t* lengths, float* out);
 /* attentions.Encoder.forward (reference attentions.py:35-47). which: 0 = enc_p.encoder,
  * 1 = pitch_predictor.pitch_net, 2 = frame_prior_net.fft_block.  x [B][H][T] in, y [B][H][T] out. */
 int64_t vsp_encoder_workspace_bytes(const vsp_ctx* ctx, int B, int T);

@@ -423,3 +423,51 @@ def test_alternative_kernel_paths_match_golden(dims, weights, golden_dir, monkey
         out = run_case(m, g)
         assert rel_err(to_np(out[0]), g["o"]) <= WAVE_TOL, case
         assert rel_err(to_np(out[2][2]), g["m_p"]) <= STAGE_TOL, case
+
+
+def test_single_call_infer_matches_three_call_path(net, golden_dir):
+    """vsp_infer (one call, caller-supplied frame padding, no host synchronisation) == vsp_encode +
+    vsp_frame_lengths_host + vsp_decode, bit for bit, and both match the reference golden."""
+    g = golden(golden_dir, "ragged_controls")
+    eng = net._engine
+    tf = int(g["x_mask"].shape[2])
+    r = eng.infer_padded(g["in_phonemes"], g["in_lengths"], g["in_sid"], tf, g["in_noise"],
+                         noise_scale=float(g["in_noise_scale"]), duration_ctl=g["in_duration"],
+                         pitch_ctl=g["in_f0"], energy_ctl=g["in_energy"])
+    ref = run_case(net, g)
+    assert torch.equal(r["o"], ref[0])
+    assert torch.equal(r["z"], ref[2][0]) and torch.equal(r["m_p"], ref[2][2])
+    np.testing.assert_array_equal(to_np(r["x_mask"]), g["x_mask"])
+    assert rel_err(to_np(r["o"]), g["o"]) <= WAVE_TOL
+    # a larger padding only appends frames: the common part of the latent is unchanged
+    tf2 = tf + 7
+    noise2 = np.zeros((g["in_noise"].shape[0], g["in_noise"].shape[1], tf2), dtype=np.float32)
+    noise2[:, :, :tf] = g["in_noise"]
+    r2 = eng.infer_padded(g["in_phonemes"], g["in_lengths"], g["in_sid"], tf2, noise2,
+                          noise_scale=float(g["in_noise_scale"]), duration_ctl=g["in_duration"],
+                          pitch_ctl=g["in_f0"], energy_ctl=g["in_energy"])
+    np.testing.assert_array_equal(to_np(r2["frame_lengths"]), to_np(r["frame_lengths"]))
+    assert rel_err(to_np(r2["m_p"][:, :, :tf]), g["m_p"]) <= STAGE_TOL
+
+
+@pytest.mark.parametrize("T,lens", [(5, [5, 3]), (37, [37, 20]), (300, [300, 123]), (1500, [1500, 1])])
+def test_attention_stage_matches_oracle(net, weights, dims, T, lens):
+    """The MFMA attention kernel alone (vsp_attention) against the closed form of reference
+    attentions.py:148-179 in the oracle: short sequences (T < window), ragged masks, and T = 1500 where the
+    key range is split over the waves of a block."""
+    from oracle.vispeech_oracle import rel_attention
+    r = np.random.Generator(np.random.PCG64(T))
+    B, H = len(lens), dims.hidden_channels
+    qkv = r.standard_normal((B, 3 * H, T)).astype(np.float32)
+    lens_a = np.array(lens, dtype=np.int64)
+    for which, layer, prefix in ((0, 1, "enc_p.encoder"), (2, 3, "frame_prior_net.fft_block")):
+        ek = torch.from_numpy(weights[f"{prefix}.attn_layers.{layer}.emb_rel_k"])
+        ev = torch.from_numpy(weights[f"{prefix}.attn_layers.{layer}.emb_rel_v"])
+        t = torch.from_numpy(qkv)
+        mask = (torch.arange(T)[None, :] < torch.from_numpy(lens_a)[:, None])
+        ref = rel_attention(t[:, :H], t[:, H:2 * H], t[:, 2 * H:], ek, ev, mask, dims.n_heads, dims.window_size)
+        out = net._engine.attention(which, layer, qkv, lens_a)
+        # rows of valid queries (masked query rows are finite garbage by design: reference gotcha G9,
+        # zeroed by the encoder's final x * mask)
+        for b, n in enumerate(lens):
+            assert rel_err(to_np(out)[b, :, :n], ref.numpy()[b, :, :n]) <= STAGE_TOL, (T, which, b)

@@ -58,6 +58,10 @@ SIGNATURES = {
     "vsp_frame_lengths_host": (_I, [_P, _P, _I, _P, C.POINTER(_I64), C.POINTER(_I64)]),
     "vsp_decode_workspace_bytes": (_I64, [_P, _I, _I, _I]),
     "vsp_decode": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _I64]),
+    "vsp_infer_workspace_bytes": (_I64, [_P, _I, _I, _I]),
+    "vsp_infer": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _F, _F, _P, _F,
+                       _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64]),
+    "vsp_attention": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "vsp_encoder_workspace_bytes": (_I64, [_P, _I, _I]),
     "vsp_encoder": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _I64]),
     "vsp_length_regulate": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),

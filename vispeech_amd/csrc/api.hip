@@ -811,7 +811,76 @@ int vsp_decode(vsp_ctx* ctx, void* stream, int B, int Tp, int Tf, int max_len, c
                      noise_scale, o, x_mask, z, z_p, m_p, logs_p);
 }
 
+// one-call form: encode + decode with a caller-supplied frame padding, no host synchronisation
+static int infer_impl(vsp_ctx* ctx, hipStream_t s, Ws& ws, int B, int Tp, int Tf, int max_len, const int64_t* phonemes,
+                      const int64_t* lengths, const int64_t* sid, const float* dctl, const float* pctl, const float* ectl,
+                      float dsc, float psc, float esc, const float* noise, float noise_scale, float* o, uint8_t* x_mask,
+                      float* z, float* z_p, float* m_p, float* logs_p, float* duration, float* f0, float* energy,
+                      int64_t* frame_lengths) {
+  const vsp_config& c = ctx->cfg;
+  float* x_var = ws.f((size_t)B * c.hidden_channels * Tp);
+  float* g = ws.f((size_t)B * c.gin_channels);
+  int32_t* cum = (int32_t*)ws.bytes((size_t)B * Tp * sizeof(int32_t));
+  const size_t mark = ws.cur;
+  int rc = encode_impl(ctx, s, ws, B, Tp, phonemes, lengths, sid, dctl, pctl, ectl, dsc, psc, esc, x_var, g, duration,
+                       f0, energy, frame_lengths, cum);
+  const size_t after_enc = ws.cur;
+  ws.cur = mark;                 // the two halves run one after the other on one stream: shared scratch
+  if (rc == VSP_OK)
+    rc = decode_impl(ctx, s, ws, B, Tp, Tf, max_len, x_var, g, cum, frame_lengths, noise, noise_scale, o, x_mask, z, z_p,
+                     m_p, logs_p);
+  ws.cur = std::max(ws.cur, after_enc);
+  return rc;
+}
+
+int64_t vsp_infer_workspace_bytes(const vsp_ctx* ctx, int B, int Tp, int tf_pad) {
+  if (!ctx || B <= 0 || Tp <= 0 || tf_pad <= 0) return VSP_ERR_ARG;
+  Ws ws(nullptr, 0, true);
+  infer_impl(const_cast<vsp_ctx*>(ctx), nullptr, ws, B, Tp, tf_pad, -1, nullptr, nullptr, nullptr, nullptr, nullptr,
+             nullptr, 1.f, 1.f, 1.f, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+             nullptr, nullptr);
+  return (int64_t)ws.cur;
+}
+
+int vsp_infer(vsp_ctx* ctx, void* stream, int B, int Tp, int tf_pad, int max_len, const int64_t* phonemes,
+              const int64_t* lengths, const int64_t* sid, const float* duration_ctl, const float* pitch_ctl,
+              const float* energy_ctl, float duration_scale, float pitch_scale, float energy_scale, const float* noise,
+              float noise_scale, float* o, uint8_t* x_mask, float* z, float* z_p, float* m_p, float* logs_p,
+              float* duration, float* f0, float* energy, int64_t* frame_lengths, void* workspace,
+              int64_t workspace_bytes) {
+  int rc = check_ready(ctx);
+  if (rc) return rc;
+  if (B <= 0 || Tp <= 0 || tf_pad <= 0 || !phonemes || !lengths || !sid || !o || !x_mask || !z || !z_p || !m_p ||
+      !logs_p || !duration || !f0 || !energy || !frame_lengths || !workspace)
+    return ctx->fail(VSP_ERR_ARG, "vsp_infer: null or non-positive argument");
+  if (!noise && noise_scale != 0.f) return ctx->fail(VSP_ERR_ARG, "vsp_infer: noise is required when noise_scale != 0");
+  const int64_t need = vsp_infer_workspace_bytes(ctx, B, Tp, tf_pad);
+  if (workspace_bytes < need)
+    return ctx->fail(VSP_ERR_WORKSPACE, "infer workspace too small: %lld < %lld bytes", (long long)workspace_bytes,
+                     (long long)need);
+  Ws ws(workspace, (size_t)workspace_bytes, false);
+  return infer_impl(ctx, (hipStream_t)stream, ws, B, Tp, tf_pad, max_len, phonemes, lengths, sid, duration_ctl, pitch_ctl,
+                    energy_ctl, duration_scale, pitch_scale, energy_scale, noise, noise_scale, o, x_mask, z, z_p, m_p,
+                    logs_p, duration, f0, energy, frame_lengths);
+}
+
 // -------------------------------------------------------------------------------------------- stages
+int vsp_attention(vsp_ctx* ctx, void* stream, int which, int layer, int B, int T, const float* qkv, const int64_t* lengths,
+                  float* out) {
+  int rc = check_ready(ctx);
+  if (rc) return rc;
+  if (which < 0 || which > 2 || B <= 0 || T <= 0 || !qkv || !lengths || !out)
+    return ctx->fail(VSP_ERR_ARG, "vsp_attention: bad argument");
+  const EncoderW& E = ctx->model.enc[which];
+  if (layer < 0 || layer >= (int)E.layers.size()) return ctx->fail(VSP_ERR_ARG, "vsp_attention: no such layer");
+  const vsp_config& c = ctx->cfg;
+  const int h = c.hidden_channels;
+  const EncLayer& L = E.layers[layer];
+  hipError_t e = launch_attention(qkv, 3L * h * T, T, ctx->arena + L.ek, ctx->arena + L.ev, lengths, out, (long)h * T, T,
+                                  B, h, c.n_heads, T, c.window_size, ctx->att_ksplit, (hipStream_t)stream);
+  return e == hipSuccess ? VSP_OK : ctx->fail(VSP_ERR_HIP, "attention: %s", hipGetErrorString(e));
+}
+
 int64_t vsp_encoder_workspace_bytes(const vsp_ctx* ctx, int B, int T) {
   if (!ctx || B <= 0 || T <= 0) return VSP_ERR_ARG;
   Ws ws(nullptr, 0, true);

@@ -177,6 +177,49 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ per-stage entry points
+    def infer_padded(self, phonemes, lengths, sid, tf_pad: int, noise, noise_scale: float = 1.0, max_len=None,
+                     duration_ctl=None, pitch_ctl=None, energy_ctl=None, duration_scale: float = 1.0,
+                     pitch_scale: float = 1.0, energy_scale: float = 1.0) -> Dict[str, torch.Tensor]:
+        """``vsp_infer``: the whole path in ONE call and without the host read of the frame counts, for
+        callers that know an upper bound ``tf_pad`` of the frame count (supplied durations / fixed max_len)."""
+        ph = _dev_i64(phonemes, self.device)
+        B, Tp = ph.shape
+        ln, sd = _dev_i64(lengths, self.device), _dev_i64(sid, self.device)
+        ctl = [None if t is None else _dev_f32(t, self.device).reshape(B, Tp) for t in (duration_ctl, pitch_ctl, energy_ctl)]
+        Tf = int(tf_pad)
+        Tdec = Tf if max_len is None else min(Tf, int(max_len))
+        inter = self.dims.inter_channels
+        ns = float(noise_scale)
+        nz = None if noise is None else _dev_f32(noise, self.device)
+        if nz is not None and tuple(nz.shape) != (B, inter, Tf):
+            raise ValueError("noise must be [B, inter_channels, tf_pad]")
+        o = self._f(B, 1, max(Tdec, 0) * self.dims.total_upsample)
+        z, z_p, m_p, logs_p = (self._f(B, inter, Tf) for _ in range(4))
+        x_mask = torch.empty((B, 1, Tf), dtype=torch.uint8, device=self.device)
+        dur, f0, en = (self._f(B, Tp) for _ in range(3))
+        fl = torch.empty(B, dtype=torch.int64, device=self.device)
+        ws = self._workspace("infer", self.lib.vsp_infer_workspace_bytes(self.ctx, B, Tp, Tf))
+        with torch.cuda.device(self.device):
+            rc = self.lib.vsp_infer(self.ctx, self._stream(), B, Tp, Tf, -1 if max_len is None else int(max_len),
+                                    _ptr(ph), _ptr(ln), _ptr(sd), _ptr(ctl[0]), _ptr(ctl[1]), _ptr(ctl[2]),
+                                    float(duration_scale), float(pitch_scale), float(energy_scale), _ptr(nz), ns,
+                                    _ptr(o), _ptr(x_mask), _ptr(z), _ptr(z_p), _ptr(m_p), _ptr(logs_p), _ptr(dur),
+                                    _ptr(f0), _ptr(en), _ptr(fl), _ptr(ws), ws.numel())
+        _lib.check(rc, self.ctx, "vsp_infer")
+        return dict(o=o, x_mask=x_mask.view(torch.bool), z=z, z_p=z_p, m_p=m_p, logs_p=logs_p, duration=dur, F0=f0,
+                    energy=en, frame_lengths=fl)
+
+    def attention(self, which: int, layer: int, qkv, lengths) -> torch.Tensor:
+        """``vsp_attention``: relative-position attention of one encoder layer on ready q|k|v [B,3H,T]."""
+        qkv = _dev_f32(qkv, self.device)
+        ln = _dev_i64(lengths, self.device)
+        B, C3, T = qkv.shape
+        out = self._f(B, C3 // 3, T)
+        with torch.cuda.device(self.device):
+            rc = self.lib.vsp_attention(self.ctx, self._stream(), which, layer, B, T, _ptr(qkv), _ptr(ln), _ptr(out))
+        _lib.check(rc, self.ctx, "vsp_attention")
+        return out
+
     def encoder(self, which: int, x, lengths) -> torch.Tensor:
         x = _dev_f32(x, self.device)
         ln = _dev_i64(lengths, self.device)
