@@ -60,7 +60,8 @@ constexpr int RP_RS = RP_CKC + 8;
 // MT = 32-row tiles per wave: 1 -> 8 waves per block (4 per SIMD with two blocks per CU, <= 128 VGPRs);
 // 2 -> 4 "fat" waves per block (2 per SIMD, up to 256 VGPRs: latency is hidden by prefetch inside the wave
 // instead of by the other waves, and only one wave of a block competes for a SIMD's matrix core)
-template <int NT, int G, int TERMS, bool PF, int MT>
+// GLDS: weight slices go global -> LDS by LDS-DMA (global_load_lds_dwordx4), as in the 128-column tile of conv_f16s.hip
+template <int NT, int G, int TERMS, bool PF, int MT, bool GLDS = false>
 __global__ void __launch_bounds__(512 / MT, 4 / MT) cl_respair_f16s(ClPairArgs a) {
   constexpr int CKC = RP_CKC, RS = RP_RS, NTH = 512 / MT, C = 32 * NT;
   constexpr int C4 = CKC / 4;                    // float4 per staged row
@@ -163,14 +164,25 @@ __global__ void __launch_bounds__(512 / MT, 4 / MT) cl_respair_f16s(ClPairArgs a
       const int blk = u * NWV + wave;
       const int ntl = blk % NT, ks = (blk / NT) % KS, g = (blk / (NT * KS)) % G, img = blk / (NT * KS * G);
       const int tap = sl * G + g;
-      wq[u] = make_uint4(0u, 0u, 0u, 0u);
+      if constexpr (!GLDS) wq[u] = make_uint4(0u, 0u, 0u, 0u);
       if (blk < NBLK && tap < K && (VSP_DIAG & 2) == 0) {
         const size_t src = (((size_t)tap * nks + chunk * KS + ks) * NT + ntl) * 64;
-        wq[u] = (img == 0 ? WHg : WLg)[src + lane];
+        if constexpr (GLDS) {
+          // slice `step` lives in ring slot step & 1; one 1 KiB fragment block per wave-instruction
+          _Float16* lp = Wb + (step & 1) * 2 * WIMG + blk * 512;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((img == 0 ? WHg : WLg) + src + lane),
+                                           (__attribute__((address_space(3))) void*)lp, 16, 0, 0);
+        } else {
+          wq[u] = (img == 0 ? WHg : WLg)[src + lane];
+        }
       }
     }
   };
   auto w_write = [&](int buf) {
+    if constexpr (GLDS) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the DMA'd slice has landed
+      return;
+    }
     uint4* dst = reinterpret_cast<uint4*>(Wb + buf * 2 * WIMG) + tid;
 #pragma unroll
     for (int u = 0; u < NWL; ++u)
@@ -424,13 +436,13 @@ extern "C" int vsp_debug_stamps(unsigned long long* host, int max_samples, int r
 }
 #endif
 
-template <int NT, int G, int TERMS, bool PF, int MT>
+template <int NT, int G, int TERMS, bool PF, int MT, bool GLDS = false>
 static hipError_t launch_pair_tile(ClPairArgs a, int B, hipStream_t s) {
   constexpr int NLc = (RP_BT + RP_HALO + 63) / 64;
   constexpr size_t lds = ((size_t)2 * NLc * 64 * RP_RS + (size_t)4 * G * (RP_CKC / 16) * NT * 512) * sizeof(_Float16);
   static_assert(lds <= 80 * 1024, "two blocks per CU");
   static bool attr_set = false;
-  auto kern = cl_respair_f16s<NT, G, TERMS, PF, MT>;
+  auto kern = cl_respair_f16s<NT, G, TERMS, PF, MT, GLDS>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
@@ -465,6 +477,9 @@ hipError_t launch_cl_pair(const ClPairArgs& a, int B, hipStream_t s) {
   if (fat < 0) { const char* e = getenv("VSP_PAIR_MT"); fat = e ? atoi(e) : 1; }
   if (a.terms == 1) return a.C == 32 ? launch_pair_tile<1, 2, 1, true, 1>(a, B, s) : launch_pair_tile<2, 1, 1, true, 1>(a, B, s);
   if (fat == 2) return a.C == 32 ? launch_pair_tile<1, 2, 3, true, 2>(a, B, s) : launch_pair_tile<2, 1, 3, true, 2>(a, B, s);
+  static int dma = -1;   // LDS-DMA weight ring (default); VSP_PAIR_GLDS=0 -> register-staged ring
+  if (dma < 0) { const char* e = getenv("VSP_PAIR_GLDS"); dma = e ? atoi(e) : 1; }
+  if (dma) return a.C == 32 ? launch_pair_tile<1, 2, 3, true, 1, true>(a, B, s) : launch_pair_tile<2, 1, 3, false, 1, true>(a, B, s);
   return a.C == 32 ? launch_pair_tile<1, 2, 3, true, 1>(a, B, s) : launch_pair_tile<2, 1, 3, false, 1>(a, B, s);
 }
 
