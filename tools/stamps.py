@@ -36,10 +36,23 @@ if os.environ.get("VSP_STAMP_CL") is not None:
     fn = lib.vsp_debug_stamps_cl
     fn.restype = C.c_int
     NS, NSTAMP = 128, 160
-    buf = np.zeros((NS, NSTAMP), dtype=np.uint64)
-    n = fn(buf.ctypes.data_as(C.c_void_p), NS, 1)
-    print(f"cl_conv_f16s launch #{os.environ['VSP_STAMP_CL']}: {n} sampled blocks (wave 0)")
+    buf2 = np.zeros((2, NS, NSTAMP), dtype=np.uint64)
+    n = fn(buf2.ctypes.data_as(C.c_void_p), 2 * NS, 1)
+    buf, cyc = buf2[0], buf2[1]
+    print(f"cl_conv_f16s launch #{os.environ['VSP_STAMP_CL']}: {n} sampled blocks (wave {os.environ.get('VSP_STAMP_WAVE', '0')})")
     s = buf[:n].astype(np.int64)
+    c = cyc[:n].astype(np.int64)
+    nz = (s > 0).sum(axis=1)
+    if n:
+        k = int(nz.min())
+        dt_us = (s[:, k - 1] - s[:, 0]) / 100.0
+        dcyc = (c[:, k - 1] - c[:, 0])
+        print(f"   shader clock over the block lifetime: median {np.median(dcyc / dt_us):.0f} MHz "
+              f"(s_memtime cycles / s_memrealtime us)")
+        # clock inside MFMA phases only (stamp 3 -> 4 is the first step's MFMA phase, then every third)
+        idx = np.arange(2, k - 3, 3)
+        mf = (c[:, idx + 1] - c[:, idx]) / np.maximum((s[:, idx + 1] - s[:, idx]) / 100.0, 1e-9)
+        print(f"   shader clock inside the MFMA phases: median {np.median(mf):.0f} MHz")
     counts = (s > 0).sum(axis=1)
     for cnt in sorted(set(counts.tolist())):
         g = s[counts == cnt][:, :cnt]

@@ -40,11 +40,14 @@ constexpr int CL_HALO = 64;  // max (K-1)*dil
 #ifdef VSP_STAMPS
 constexpr int CL_NSTAMP = 160, CL_NSAMPLE = 128;
 __device__ unsigned long long g_cl_stamps[CL_NSAMPLE][CL_NSTAMP];
+__device__ unsigned long long g_cl_cycles[CL_NSAMPLE][CL_NSTAMP];   // s_memtime (shader clock) at the same points
 __device__ unsigned g_cl_stamp_count;
 #define CL_STAMP()                                                          \
   do {                                                                      \
-    if (stamp_slot >= 0 && stamp_n < CL_NSTAMP && lane == 0)                \
+    if (stamp_slot >= 0 && stamp_n < CL_NSTAMP && lane == 0) {              \
       g_cl_stamps[stamp_slot][stamp_n] = __builtin_amdgcn_s_memrealtime();  \
+      g_cl_cycles[stamp_slot][stamp_n] = __builtin_readcyclecounter();      \
+    }                                                                       \
     ++stamp_n;                                                              \
   } while (0)
 #else
@@ -494,6 +497,9 @@ extern "C" int vsp_debug_stamps_cl(unsigned long long* host, int max_samples, in
   if ((int)n > max_samples) n = max_samples;
   if (n > (unsigned)CL_NSAMPLE) n = CL_NSAMPLE;
   (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_cl_stamps), (size_t)n * CL_NSTAMP * sizeof(unsigned long long));
+  if (max_samples >= 2 * CL_NSAMPLE)   // caller's buffer has room for the cycle counters behind the stamps
+    (void)hipMemcpyFromSymbol(host + (size_t)CL_NSAMPLE * CL_NSTAMP, HIP_SYMBOL(g_cl_cycles),
+                              (size_t)n * CL_NSTAMP * sizeof(unsigned long long));
   if (reset) { const unsigned z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cl_stamp_count), &z, sizeof z); }
   return (int)n;
 }
