@@ -408,6 +408,13 @@ void run_generator_cl(Run& r, int B, int T, T3 z, const int64_t* in_lengths, con
   }
   float* buf[5];
   for (auto& bptr : buf) bptr = r.ws.f((size_t)B * mx);
+  // the channels-last kernels address one utterance's tensor with 32-bit byte offsets (buffer descriptors)
+  if (mx * sizeof(float) >= (size_t)1 << 31) {
+    if (r.rc == VSP_OK)
+      r.rc = r.ctx->fail(VSP_ERR_UNSUPPORTED, "generator: %d frames per call exceed the 2 GiB per-utterance activation "
+                                              "limit; synthesise in chunks (Engine.generator_stream)", T);
+    return;
+  }
   ConvArgs a = r.args(m.g_pre, z, X0, T, T);
   a.lengths = in_lengths; a.in_mask = in_lengths ? 1 : 0;
   a.cond = gc; a.cond_bs = c0;
