@@ -91,9 +91,14 @@ void pack_cl_weights(uint16_t* hi, uint16_t* lo, int Cout, int Cin, int K, int p
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // VSP_DIAG: timing-only ablation builds (tools/ablate.sh); bit 0 no MFMA, bit 1 no weight-slice loads,
-// bit 2 no activation loads, bit 3 no epilogue memory traffic.  0 in the product build.
+// bit 2 no activation loads, bit 3 no epilogue memory traffic, bit 4 no barriers.  0 in the product build.
 #ifndef VSP_DIAG
 #define VSP_DIAG 0
+#endif
+#if VSP_DIAG & 16
+#define CL_SYNC() ((void)0)      // timing-only: no barriers
+#else
+#define CL_SYNC() __syncthreads()
 #endif
 
 // TERMS = 3: fp32-accurate split product (default).  TERMS = 1: plain f16 operands (hi images only,
@@ -313,7 +318,7 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
     if (d < nsteps) w_issue(d, wq[d % WD]);
   if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   CL_STAMP();                                   // 1: first window + slice staged
-  __syncthreads();
+  CL_SYNC();
   CL_STAMP();                                   // 2: barrier
   f16x8 xhA[MT], xlA[MT], whA[NT], wlA[NT];
   [[maybe_unused]] f16x8 xhB[MT], xlB[MT], whB[NT], wlB[NT];
@@ -348,12 +353,12 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
     CL_STAMP();                                 // step: MFMAs done
     if (more) {
       if (new_chunk) {
-        __syncthreads();          // every wave is done reading the activation window
+        CL_SYNC();          // every wave is done reading the activation window
         x_write();
       }
       w_write((step + 1) & 1, st);  // the other ring slot: last read one barrier ago
       CL_STAMP();                               // step: next slice (and window) written
-      __syncthreads();
+      CL_SYNC();
       CL_STAMP();                               // step: barrier
     }
   };
@@ -411,13 +416,13 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
       CL_STAMP();                               // step: MFMAs done
       if (more) {
         if (new_chunk) {
-          __syncthreads();
+          CL_SYNC();
           x_write();
         }
         if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA'd slice has landed
         else w_write((step + 1) & 1, wq[0]);
         CL_STAMP();                             // step: next slice (and window) in LDS
-        __syncthreads();
+        CL_SYNC();
         CL_STAMP();                             // step: barrier
       }
     }
