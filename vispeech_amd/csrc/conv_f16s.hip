@@ -223,35 +223,47 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
   static_assert(!GLDS || WD == 1, "the LDS-DMA ring runs one slice ahead");
   uint4 wq[WD][NWL];
   // LDS-DMA variant of w_issue + w_write: slice `step` -> ring slot `buf`
-  auto w_dma = [&](int step, int buf) {
-    const int chunk = step / ns, sl = step - chunk * ns;
+  // per-wave constants of the slice copy: block u*NWV + wave of a slice is fragment block (img, g, ks, ntl);
+  // its source offset (in 16-byte units) is wslice(chunk, tap0) + wblk[u], so a step costs one 64-bit
+  // multiply-add instead of four index chains (PMC: 3.4 scalar instructions per MFMA before this)
+  const size_t w_tap = (size_t)nks * nnt * 64;                       // one tap
+  const size_t w_base = ((size_t)ph * a.K * nks * nnt + (size_t)cb * NTB) * 64;
+  size_t wblk[NWL];
+  int wg[NWL];
+  bool wlo[NWL];
+#pragma unroll
+  for (int u = 0; u < NWL; ++u) {
+    const int blk = u * NWV + wave;
+    const int ntl = blk % NTB, ks = (blk / NTB) % KS, g = (blk / (NTB * KS)) % G, img = blk / (NTB * KS * G);
+    wblk[u] = w_base + (size_t)g * w_tap + ((size_t)ks * nnt + ntl) * 64;
+    wg[u] = g;
+    wlo[u] = img != 0;
+  }
+  auto w_dma = [&](int chunk, int sl, int buf) {
+    const size_t wslice = (size_t)(sl * G) * w_tap + (size_t)chunk * KS * nnt * 64;
 #pragma unroll
     for (int u = 0; u < NWL; ++u) {
       const int blk = u * NWV + wave;
-      const int ntl = blk % NTB, ks = (blk / NTB) % KS, g = (blk / (NTB * KS)) % G, img = blk / (NTB * KS * G);
-      const int tap = sl * G + g;
-      if (blk < NBLK && tap < a.K && (VSP_DIAG & 2) == 0) {
-        const size_t src = ((((size_t)ph * a.K + tap) * nks + chunk * KS + ks) * nnt + cb * NTB + ntl) * 64;
-        const uint4* gp = (img == 0 ? WHg : WLg) + src + lane;
+      if (blk < NBLK && sl * G + wg[u] < a.K && (VSP_DIAG & 2) == 0) {
+        const uint4* gp = (wlo[u] ? WLg : WHg) + (wslice + wblk[u]) + lane;
         _Float16* lp = Wb + buf * 2 * WIMG + blk * 512;     // 1 KiB per fragment block, wave-uniform
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
                                          (__attribute__((address_space(3))) void*)lp, 16, 0, 0);
       }
     }
   };
-  auto w_issue = [&](int step, uint4(&wv)[NWL]) {
-    const int chunk = step / ns, sl = step - chunk * ns;
+  auto w_issue_cs = [&](int chunk, int sl, uint4(&wv)[NWL]) {
+    const size_t wslice = (size_t)(sl * G) * w_tap + (size_t)chunk * KS * nnt * 64;
 #pragma unroll
     for (int u = 0; u < NWL; ++u) {
       const int blk = u * NWV + wave;
-      const int ntl = blk % NTB, ks = (blk / NTB) % KS, g = (blk / (NTB * KS)) % G, img = blk / (NTB * KS * G);
-      const int tap = sl * G + g;
       wv[u] = make_uint4(0u, 0u, 0u, 0u);
-      if (blk < NBLK && tap < a.K && (VSP_DIAG & 2) == 0) {
-        const size_t src = ((((size_t)ph * a.K + tap) * nks + chunk * KS + ks) * nnt + cb * NTB + ntl) * 64;
-        wv[u] = (img == 0 ? WHg : WLg)[src + lane];
-      }
+      if (blk < NBLK && sl * G + wg[u] < a.K && (VSP_DIAG & 2) == 0) wv[u] = (wlo[u] ? WLg : WHg)[wslice + wblk[u] + lane];
     }
+  };
+  auto w_issue = [&](int step, uint4(&wv)[NWL]) {      // step-indexed form of the deeper (WD >= 2) queues
+    const int chunk = step / ns;
+    w_issue_cs(chunk, step - chunk * ns, wv);
   };
   auto w_write = [&](int buf, const uint4(&wv)[NWL]) {
     uint4* dst = reinterpret_cast<uint4*>(Wb + buf * 2 * WIMG) + tid;
@@ -309,8 +321,8 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
   };
 
   x_issue(0);
-  if constexpr (GLDS) w_dma(0, 0);
-  else w_issue(0, wq[0]);
+  if constexpr (GLDS) w_dma(0, 0, 0);
+  else w_issue_cs(0, 0, wq[0]);
   x_write();
   if constexpr (!GLDS) w_write(0, wq[0]);
 #pragma unroll
@@ -367,13 +379,15 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
   if constexpr (WD == 1) {
     // plain loop (kept literally separate from step_body: the register allocation of this form
     // fits the 128-VGPR budget of the two-blocks-per-CU tiles)
+    int chunk = 0, sl = 0;                        // (chunk, slice) of the current step, kept incrementally
     for (int step = 0; step < nsteps; ++step) {
-      const int chunk = step / ns, sl = step - chunk * ns;
       const bool more = step + 1 < nsteps;
-      const bool new_chunk = more && sl == ns - 1;
+      const bool last_sl = sl == ns - 1;
+      const bool new_chunk = more && last_sl;
+      const int chunk_n = last_sl ? chunk + 1 : chunk, sl_n = last_sl ? 0 : sl + 1;   // of step + 1
       if (more) {
-        if constexpr (GLDS) w_dma(step + 1, (step + 1) & 1);   // that slot was last read one barrier ago
-        else w_issue(step + 1, wq[0]);
+        if constexpr (GLDS) w_dma(chunk_n, sl_n, (step + 1) & 1);   // that slot was last read one barrier ago
+        else w_issue_cs(chunk_n, sl_n, wq[0]);
       }
       if (new_chunk) x_issue(chunk + 1);
       const _Float16* Wc = Wb + (step & 1) * 2 * WIMG;
@@ -425,6 +439,8 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
         CL_SYNC();
         CL_STAMP();                             // step: barrier
       }
+      chunk = chunk_n;
+      sl = sl_n;
     }
   } else if constexpr (WD == 2) {
     for (int step = 0; step < nsteps; step += 2) {
