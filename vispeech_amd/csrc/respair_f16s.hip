@@ -153,27 +153,38 @@ __global__ void __launch_bounds__(512 / MT, 4 / MT) cl_respair_f16s(ClPairArgs a
   //      cl_conv_f16s; fragment-block index ((img*G + g)*KS + ks)*NT + ntl is wave-uniform
   const int nks = C >> 4;
   uint4 wq[NWL];
-  auto w_issue = [&](int step) {
-    const int cv = step >= nsteps1 ? 1 : 0;
-    const int s1 = step - cv * nsteps1;
-    const int chunk = s1 / ns, sl = s1 - chunk * ns;
+  // per-wave constants of the slice copy (fragment block u*NWV + wave = (img, g, ks, ntl)); a slice then costs
+  // one 64-bit multiply-add instead of per-block index chains and per-step divisions
+  const size_t w_tap = (size_t)nks * NT * 64;                        // one tap, in 16-byte units
+  size_t wblk[NWL];
+  int wg[NWL];
+  bool wlo[NWL];
+#pragma unroll
+  for (int u = 0; u < NWL; ++u) {
+    const int blk = u * NWV + wave;
+    const int ntl = blk % NT, ks = (blk / NT) % KS, g = (blk / (NT * KS)) % G, img = blk / (NT * KS * G);
+    wblk[u] = (size_t)g * w_tap + ((size_t)ks * NT + ntl) * 64;
+    wg[u] = g;
+    wlo[u] = img != 0;
+  }
+  // slice (conv cv, chunk, sl) -> ring slot `slot` (GLDS) or the staging registers
+  auto w_issue = [&](int cv, int chunk, int sl, int slot) {
     const uint4* WHg = reinterpret_cast<const uint4*>(cv ? a.w2h : a.w1h);
     const uint4* WLg = reinterpret_cast<const uint4*>(cv ? a.w2l : a.w1l);
+    const size_t wslice = (size_t)(sl * G) * w_tap + (size_t)chunk * KS * NT * 64;
 #pragma unroll
     for (int u = 0; u < NWL; ++u) {
       const int blk = u * NWV + wave;
-      const int ntl = blk % NT, ks = (blk / NT) % KS, g = (blk / (NT * KS)) % G, img = blk / (NT * KS * G);
-      const int tap = sl * G + g;
       if constexpr (!GLDS) wq[u] = make_uint4(0u, 0u, 0u, 0u);
-      if (blk < NBLK && tap < K && (VSP_DIAG & 2) == 0) {
-        const size_t src = (((size_t)tap * nks + chunk * KS + ks) * NT + ntl) * 64;
+      if (blk < NBLK && sl * G + wg[u] < K && (VSP_DIAG & 2) == 0) {
+        const uint4* gp = (wlo[u] ? WLg : WHg) + (wslice + wblk[u]) + lane;
         if constexpr (GLDS) {
-          // slice `step` lives in ring slot step & 1; one 1 KiB fragment block per wave-instruction
-          _Float16* lp = Wb + (step & 1) * 2 * WIMG + blk * 512;
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((img == 0 ? WHg : WLg) + src + lane),
+          // one 1 KiB fragment block per wave-instruction, straight into the ring slot
+          _Float16* lp = Wb + slot * 2 * WIMG + blk * 512;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
                                            (__attribute__((address_space(3))) void*)lp, 16, 0, 0);
         } else {
-          wq[u] = (img == 0 ? WHg : WLg)[src + lane];
+          wq[u] = *gp;
         }
       }
     }
@@ -299,17 +310,21 @@ __global__ void __launch_bounds__(512 / MT, 4 / MT) cl_respair_f16s(ClPairArgs a
   // ================= conv1 =================
   init_acc(a.b1);
   x_issue(0);
-  w_issue(0);
+  w_issue(0, 0, 0, 0);
   RP_STAMP();                                   // 1: loads issued
   x_write();
   w_write(0);
   RP_STAMP();                                   // 2: window converted + written (includes the load latency)
   RP_SYNC();
   RP_STAMP();                                   // 3: barrier
+  int chunk = 0, sl = 0;                          // of the current step, kept incrementally
   for (int step = 0; step < nsteps1; ++step) {
-    const int chunk = step / ns, sl = step - chunk * ns;
-    const bool new_chunk = (NCH > 1) && sl == ns - 1 && chunk + 1 < NCH;
-    w_issue(step + 1);                          // conv2's first slice follows conv1's last
+    const bool last_sl = sl == ns - 1;
+    const bool new_chunk = (NCH > 1) && last_sl && chunk + 1 < NCH;
+    const int chunk_n = last_sl ? chunk + 1 : chunk, sl_n = last_sl ? 0 : sl + 1;
+    // next slice; conv2's first slice follows conv1's last
+    if (chunk_n < NCH) w_issue(0, chunk_n, sl_n, (step + 1) & 1);
+    else w_issue(1, 0, 0, (step + 1) & 1);
     if (new_chunk) x_issue(chunk + 1);
     slice(step, sl, a.dil);
     RP_STAMP();                                 // conv1 step: MFMAs done
@@ -321,6 +336,8 @@ __global__ void __launch_bounds__(512 / MT, 4 / MT) cl_respair_f16s(ClPairArgs a
     RP_STAMP();                                 // conv1 step: next slice written (includes its fetch latency)
     RP_SYNC();
     RP_STAMP();                                 // conv1 step: barrier
+    chunk = chunk_n;
+    sl = sl_n;
   }
 
   // conv1 tile -> fp32 values (bias is in hh), rows outside the utterance are conv2's zero padding
@@ -364,7 +381,10 @@ __global__ void __launch_bounds__(512 / MT, 4 / MT) cl_respair_f16s(ClPairArgs a
     for (int sl = 0; sl < ns; ++sl) {
       const int step = nsteps1 + c2 * ns + sl;
       const bool more = step + 1 < nsteps;
-      if (more) w_issue(step + 1);
+      if (more) {
+        if (sl + 1 < ns) w_issue(1, c2, sl + 1, (step + 1) & 1);
+        else w_issue(1, c2 + 1, 0, (step + 1) & 1);
+      }
       slice(step, sl, 1);
       RP_STAMP();                               // conv2 step: MFMAs done
       if (more) {
