@@ -244,7 +244,8 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
 #pragma unroll
     for (int u = 0; u < NWL; ++u) {
       const int blk = u * NWV + wave;
-      if (blk < NBLK && sl * G + wg[u] < a.K && (VSP_DIAG & 2) == 0) {
+      // (NBLK % NWV == 0 and one tap per slice make both tests compile-time true: straight-line issue)
+      if ((NBLK % NWV == 0 || blk < NBLK) && (G == 1 || sl * G + wg[u] < a.K) && (VSP_DIAG & 2) == 0) {
         const uint4* gp = (wlo[u] ? WLg : WHg) + (wslice + wblk[u]) + lane;
         _Float16* lp = Wb + buf * 2 * WIMG + blk * 512;     // 1 KiB per fragment block, wave-uniform
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
