@@ -74,6 +74,7 @@ struct ClPairArgs {
   int acc_prev; float div;                  // out = (result + out) / div
   int terms;                                // 3 = split product, 1 = plain f16 operands
   int tiles;                                // set by the launcher: tiles per utterance
+  int xrows;                                // set by the launcher: staged window rows
 };
 bool cl_pair_supported(int C, int K, int dil);
 hipError_t launch_cl_pair(const ClPairArgs& a, int B, hipStream_t s);

@@ -61,7 +61,9 @@ constexpr int RP_RS = RP_CKC + 8;
 // 2 -> 4 "fat" waves per block (2 per SIMD, up to 256 VGPRs: latency is hidden by prefetch inside the wave
 // instead of by the other waves, and only one wave of a block competes for a SIMD's matrix core)
 // GLDS: weight slices go global -> LDS by LDS-DMA (global_load_lds_dwordx4), as in the 128-column tile of conv_f16s.hip
-template <int NT, int G, int TERMS, bool PF, int MT, bool GLDS = false>
+// XW: the window holds exactly 256 + (K-1)*dil rows (a.xrows) and sits BEHIND the ring in LDS, so that a ring of
+// twice the taps per slot still leaves room for two blocks per CU
+template <int NT, int G, int TERMS, bool PF, int MT, bool GLDS = false, bool XW = false>
 __global__ void __launch_bounds__(512 / MT, 4 / MT) cl_respair_f16s(ClPairArgs a) {
   constexpr int CKC = RP_CKC, RS = RP_RS, NTH = 512 / MT, C = 32 * NT;
   constexpr int C4 = CKC / 4;                    // float4 per staged row
@@ -69,15 +71,17 @@ __global__ void __launch_bounds__(512 / MT, 4 / MT) cl_respair_f16s(ClPairArgs a
   constexpr int NL = (RP_BT + RP_HALO + ROWS_PER_U - 1) / ROWS_PER_U;
   constexpr int WMAX = NL * ROWS_PER_U;          // 320 staged rows
   constexpr int KS = CKC / 16;
-  constexpr int XIMG = WMAX * RS;                // halfs per activation image
+  [[maybe_unused]] constexpr int XIMG_MAX = WMAX * RS;   // halfs per activation image at the full halo
   constexpr int WIMG = G * KS * NT * 64 * 8;     // halfs per weight-slice image
   constexpr int NWV = NTH / 64;
   constexpr int NBLK = (TERMS == 3 ? 2 : 1) * G * KS * NT;
   constexpr int NWL = (NBLK + NWV - 1) / NWV;
   constexpr int NCH = NT;                        // 32-channel chunks of the contraction
   extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
-  _Float16* const Xh = lds;                      // [WMAX][RS] hi, then lo: x window, later the t image
-  _Float16* const Wb = lds + 2 * XIMG;
+  // [rows][RS] hi, then lo: x window, later the t image; the weight ring before (XW) or after it
+  _Float16* const Xh = XW ? lds + 4 * WIMG : lds;
+  _Float16* const Wb = XW ? lds : lds + 2 * XIMG_MAX;
+  const int XIMG = XW ? a.xrows * RS : XIMG_MAX;
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -117,13 +121,19 @@ __global__ void __launch_bounds__(512 / MT, 4 / MT) cl_respair_f16s(ClPairArgs a
   const int st_voff = (st_row * C + 4 * st_c4) * 4;
   const int st_loff = st_row * RS + 4 * st_c4;
   u32x4 sv[NL];
+  bool st_tail[NL];                              // XW: is this lane's row of sweep u inside the window?
+#pragma unroll
+  for (int u = 0; u < NL; ++u) st_tail[u] = st_row + u * ROWS_PER_U < a.xrows;
   const float slope = a.slope;
   auto x_issue = [&](int chunk) {
     const int base = ((t0 - p2 - p1) * C + chunk * CKC) * 4;
 #pragma unroll
-    for (int u = 0; u < NL; ++u)
-      sv[u] = (VSP_DIAG & 4) ? u32x4{1u, 2u, 3u, 4u}
-                             : __builtin_amdgcn_raw_buffer_load_b128(rx, st_voff + (base + u * ROWS_PER_U * C * 4), 0, 0);
+    for (int u = 0; u < NL; ++u) {
+      // XW: lanes of the last sweep that fall behind the window read from an out-of-range offset (returns 0)
+      const int off = st_voff + (base + u * ROWS_PER_U * C * 4);
+      const bool in = !XW || (u + 1) * ROWS_PER_U <= RP_BT || st_tail[u];
+      sv[u] = (VSP_DIAG & 4) ? u32x4{1u, 2u, 3u, 4u} : __builtin_amdgcn_raw_buffer_load_b128(rx, in ? off : 0x7ffffff0, 0, 0);
+    }
   };
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -144,8 +154,10 @@ __global__ void __launch_bounds__(512 / MT, 4 / MT) cl_respair_f16s(ClPairArgs a
         el[2 * k] = xl.x; el[2 * k + 1] = xl.y;
       }
       _Float16* dst = Xh + st_loff + u * (ROWS_PER_U * RS);
-      *reinterpret_cast<f16x4*>(dst) = eh;
-      if constexpr (TERMS == 3) *reinterpret_cast<f16x4*>(dst + XIMG) = el;
+      if (!XW || (u + 1) * ROWS_PER_U <= RP_BT || st_tail[u]) {
+        *reinterpret_cast<f16x4*>(dst) = eh;
+        if constexpr (TERMS == 3) *reinterpret_cast<f16x4*>(dst + XIMG) = el;
+      }
     }
   };
 
@@ -273,21 +285,25 @@ __global__ void __launch_bounds__(512 / MT, 4 / MT) cl_respair_f16s(ClPairArgs a
     const _Float16* Wc = Wb + (step & 1) * 2 * WIMG;
     const int tap0 = sl * G;
     const int nit = ((K - tap0) < G ? (K - tap0) : G) * KS;
-    if constexpr (PF && (NT == 1 || MT == 2) && G * KS == 4) {
-      // 32-channel tile: registers to spare -- all fragments of the slice are requested before its
-      // first MFMA (one LDS round trip per slice instead of one per k-step: 3 MFMAs do not cover it)
+    if constexpr (PF && (NT == 1 || MT == 2) && (G * KS) % 4 == 0) {
+      // registers to spare: the fragments of four k-steps (two taps) are requested before the first of their
+      // MFMAs (one LDS round trip per four k-steps instead of one per k-step: 3 MFMAs do not cover it)
       f16x8 xhC[MT], xlC[MT], whC[NT], wlC[NT], xhD[MT], xlD[MT], whD[NT], wlD[NT];
-      load_frags(Wc, tap0 * rowstep, 0, xhA, xlA, whA, wlA);
-      load_frags(Wc, tap0 * rowstep, 1, xhB, xlB, whB, wlB);
-      if (nit > 2) {
-        load_frags(Wc, (tap0 + 1) * rowstep, 2, xhC, xlC, whC, wlC);
-        load_frags(Wc, (tap0 + 1) * rowstep, 3, xhD, xlD, whD, wlD);
-      }
-      mma(xhA, xlA, whA, wlA);
-      mma(xhB, xlB, whB, wlB);
-      if (nit > 2) {
-        mma(xhC, xlC, whC, wlC);
-        mma(xhD, xlD, whD, wlD);
+      for (int i0 = 0; i0 < nit; i0 += 4) {
+        const int t_a = (tap0 + i0 / KS) * rowstep, t_b = (tap0 + i0 / KS + 1) * rowstep;
+        const bool four = nit - i0 > 2;
+        load_frags(Wc, t_a, i0, xhA, xlA, whA, wlA);
+        load_frags(Wc, t_a, i0 + 1, xhB, xlB, whB, wlB);
+        if (four) {
+          load_frags(Wc, t_b, i0 + 2, xhC, xlC, whC, wlC);
+          load_frags(Wc, t_b, i0 + 3, xhD, xlD, whD, wlD);
+        }
+        mma(xhA, xlA, whA, wlA);
+        mma(xhB, xlB, whB, wlB);
+        if (four) {
+          mma(xhC, xlC, whC, wlC);
+          mma(xhD, xlD, whD, wlD);
+        }
       }
     } else if constexpr (PF) {
       load_frags(Wc, tap0 * rowstep, 0, xhA, xlA, whA, wlA);
@@ -456,16 +472,21 @@ extern "C" int vsp_debug_stamps(unsigned long long* host, int max_samples, int r
 }
 #endif
 
-template <int NT, int G, int TERMS, bool PF, int MT, bool GLDS = false>
+template <int NT, int G, int TERMS, bool PF, int MT, bool GLDS = false, bool XW = false>
 static hipError_t launch_pair_tile(ClPairArgs a, int B, hipStream_t s) {
   constexpr int NLc = (RP_BT + RP_HALO + 63) / 64;
-  constexpr size_t lds = ((size_t)2 * NLc * 64 * RP_RS + (size_t)4 * G * (RP_CKC / 16) * NT * 512) * sizeof(_Float16);
-  static_assert(lds <= 80 * 1024, "two blocks per CU");
+  constexpr size_t ring = (size_t)4 * G * (RP_CKC / 16) * NT * 512 * sizeof(_Float16);
+  constexpr size_t lds_full = (size_t)2 * NLc * 64 * RP_RS * sizeof(_Float16) + ring;
+  // XW: 2 x (256 + 50) rows x 80 B + ring; two blocks per CU need <= 80 KiB each at the layers' real halos
+  static_assert(XW || lds_full <= 80 * 1024, "two blocks per CU");
+  static_assert(!XW || (size_t)2 * (RP_BT + 50) * RP_RS * sizeof(_Float16) + ring <= 80 * 1024, "two blocks per CU");
+  a.xrows = XW ? RP_BT + (a.K - 1) * a.dil : NLc * 64;   // even (K odd): both images stay 16-byte aligned
+  const size_t lds = XW ? (size_t)2 * a.xrows * RP_RS * sizeof(_Float16) + ring : lds_full;
   static bool attr_set = false;
-  auto kern = cl_respair_f16s<NT, G, TERMS, PF, MT, GLDS>;
+  auto kern = cl_respair_f16s<NT, G, TERMS, PF, MT, GLDS, XW>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
+                                       (int)lds_full);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
@@ -499,6 +520,9 @@ hipError_t launch_cl_pair(const ClPairArgs& a, int B, hipStream_t s) {
   if (fat == 2) return a.C == 32 ? launch_pair_tile<1, 2, 3, true, 2>(a, B, s) : launch_pair_tile<2, 1, 3, true, 2>(a, B, s);
   static int dma = -1;   // LDS-DMA weight ring (default); VSP_PAIR_GLDS=0 -> register-staged ring
   if (dma < 0) { const char* e = getenv("VSP_PAIR_GLDS"); dma = e ? atoi(e) : 1; }
+  static int xw = -1;    // exact window rows + ring slots of twice the taps (default); VSP_PAIR_XW=0 -> 320-row window
+  if (xw < 0) { const char* e = getenv("VSP_PAIR_XW"); xw = e ? atoi(e) : 1; }
+  if (dma && xw) return a.C == 32 ? launch_pair_tile<1, 4, 3, true, 1, true, true>(a, B, s) : launch_pair_tile<2, 2, 3, false, 1, true, true>(a, B, s);
   if (dma) return a.C == 32 ? launch_pair_tile<1, 2, 3, true, 1, true>(a, B, s) : launch_pair_tile<2, 1, 3, false, 1, true>(a, B, s);
   return a.C == 32 ? launch_pair_tile<1, 2, 3, true, 1>(a, B, s) : launch_pair_tile<2, 1, 3, false, 1>(a, B, s);
 }
