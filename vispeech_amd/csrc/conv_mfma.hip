@@ -82,7 +82,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // image; time contiguous, same bytes as the f32 window): a B fragment (8 consecutive ci of one time
 // column) is four conflict-free ds_read_b32, and staging stays a 16-byte ds_write per four columns.
 template <int MT, int NT, int WM, int WN, bool F16S>
-__global__ void __launch_bounds__(64 * WM * WN) conv1d_f32_mfma(ConvArgs a) {
+__global__ void __launch_bounds__(64 * WM * WN, F16S ? 2 : 1) conv1d_f32_mfma(ConvArgs a) {
   constexpr int BN = 32 * NT * WN;
   constexpr int LWP = BN + CONV_HALO;
   constexpr int NW = WM * WN;
