@@ -30,7 +30,7 @@ constexpr int ATT_RS = 17;    // row stride of the relative tables (2w+1 <= 16)
 // split NW ways inside the block; row statistics are merged through LDS after pass 1 and the partial O^T
 // tiles are summed through LDS at the end -- NW x the blocks for the same MFMA work.
 template <int DK, int NW, bool KSPLIT>
-__global__ void __launch_bounds__(64 * NW) attn_relpos_f32(const float* __restrict__ qkv, long bs, long cs,
+__global__ void __launch_bounds__(64 * NW, KSPLIT ? 1 : 2) attn_relpos_f32(const float* __restrict__ qkv, long bs, long cs,
                                                        const float* __restrict__ emb_k,
                                                        const float* __restrict__ emb_v,
                                                        const int64_t* __restrict__ lengths,
