@@ -360,18 +360,31 @@ __global__ void __launch_bounds__(512 / MT, 4 / MT) cl_respair_f16s(ClPairArgs a
   float tv[MT][NT][16];
   {
     const int tt = t0 - p2 + row0 + 4 * h;      // time of D register 0 of this lane (tile mt adds 32*mt)
+    // interior waves (every row of the wave inside the utterance: all but the first and last tiles) skip the
+    // per-row range test -- wave-uniform branch
+    const int tw = t0 - p2 + row0;
+    const bool interior = tw >= 0 && tw + 32 * MT <= a.T;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int t = tt + mt * 32 + (r & 3) + 8 * (r >> 2);
           float v = TERMS == 3 ? hh[mt][nt][r] + cr[mt][nt][r] * (1.f / 2048.f) : hh[mt][nt][r];
           const float y = v * slope;
-          v = v > y ? v : y;                    // leaky-relu (0 <= slope <= 1)
-          tv[mt][nt][r] = (t >= 0 && t < a.T) ? v : 0.f;
+          tv[mt][nt][r] = v > y ? v : y;        // leaky-relu (0 <= slope <= 1)
         }
+    if (!interior) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int t = tt + mt * 32 + (r & 3) + 8 * (r >> 2);
+            if (!(t >= 0 && t < a.T)) tv[mt][nt][r] = 0.f;
+          }
+    }
   }
 
   // ================= conv2 =================
@@ -420,10 +433,12 @@ __global__ void __launch_bounds__(512 / MT, 4 / MT) cl_respair_f16s(ClPairArgs a
     const int mt = mn / NT, nt = mn % NT;
     const int lo = (t0 + row0 + mt * 32 + 4 * h) * ts + (nt * 32 + l31) * 4;
     int off[16];
+    const bool whole = row0 + mt * 32 + 32 <= R2;   // wave-uniform: only the block's last tile straddles R2
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int rr = (r & 3) + 8 * (r >> 2);
-      off[r] = (row0 + mt * 32 + 4 * h + rr) < R2 ? lo + rr * ts : 0x7ffffff0;   // out of range: load 0 / store dropped
+      off[r] = lo + rr * ts;
+      if (!whole && (row0 + mt * 32 + 4 * h + rr) >= R2) off[r] = 0x7ffffff0;   // out of range: load 0 / store dropped
     }
     float v[16], rv[16];
 #pragma unroll
