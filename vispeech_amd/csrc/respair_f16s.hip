@@ -372,7 +372,8 @@ __global__ void __launch_bounds__(512 / MT, 4 / MT) cl_respair_f16s(ClPairArgs a
         for (int r = 0; r < 16; ++r) {
           float v = TERMS == 3 ? hh[mt][nt][r] + cr[mt][nt][r] * (1.f / 2048.f) : hh[mt][nt][r];
           const float y = v * slope;
-          tv[mt][nt][r] = v > y ? v : y;        // leaky-relu (0 <= slope <= 1)
+          asm("v_max_f32 %0, %1, %2" : "=v"(v) : "v"(v), "v"(y));   // leaky-relu = max(v, slope*v), 0 <= slope <= 1
+          tv[mt][nt][r] = v;
         }
     if (!interior) {
 #pragma unroll
@@ -396,12 +397,20 @@ __global__ void __launch_bounds__(512 / MT, 4 / MT) cl_respair_f16s(ClPairArgs a
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       _Float16* dst = Xh + (row0 + mt * 32 + 4 * h) * RS + l31;
+      // two rows at a time so that the conversions use the packed forms (v_cvt_pk_f16_f32, v_pk_add / v_pk_mul)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float v = tv[mt][c2][r];
-        const _Float16 vh = (_Float16)v;
-        dst[((r & 3) + 8 * (r >> 2)) * RS] = vh;
-        if constexpr (TERMS == 3) dst[((r & 3) + 8 * (r >> 2)) * RS + XIMG] = (_Float16)((v - (float)vh) * 2048.f);
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 v = {tv[mt][c2][r], tv[mt][c2][r + 1]};
+        const f16x2 vh = __builtin_convertvector(v, f16x2);
+        const f32x2 back = __builtin_convertvector(vh, f32x2);
+        const f16x2 vl = __builtin_convertvector((v - back) * 2048.f, f16x2);
+        const int o0 = ((r & 3) + 8 * (r >> 2)) * RS, o1 = (((r + 1) & 3) + 8 * ((r + 1) >> 2)) * RS;
+        dst[o0] = vh.x;
+        dst[o1] = vh.y;
+        if constexpr (TERMS == 3) {
+          dst[o0 + XIMG] = vl.x;
+          dst[o1 + XIMG] = vl.y;
+        }
       }
     }
     RP_STAMP();                                 // t image written
