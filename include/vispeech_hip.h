@@ -202,6 +202,14 @@ int vsp_posterior_encoder(vsp_ctx* ctx, void* stream, int B, int T, const float*
 /* ResidualCouplingBlock.forward(reverse=False) (reference models.py:202-206). z -> z_p. */
 int vsp_flow_forward(vsp_ctx* ctx, void* stream, int B, int Tf, const float* z, const float* g,
                      const int64_t* frame_lengths, float* z_p, void* workspace, int64_t workspace_bytes);
+/* Linear spectrogram of mel_processing.spectrogram_torch (reference mel_processing.py:50-69), the input of
+ * voice_conversion: reflect-pad (n_fft - hop)/2 on both sides, periodic Hann window of n_fft, one-sided DFT
+ * (n_fft = 2 * (cfg.spec_channels - 1)), magnitude sqrt(re^2 + im^2 + 1e-6).  audio [B][L] (device),
+ * spec [B][spec_channels][T] with T = vsp_spectrogram_frames(L, hop); needs cfg.spec_channels > 0. */
+int vsp_spectrogram_frames(const vsp_ctx* ctx, int L, int hop);
+int64_t vsp_spectrogram_workspace_bytes(const vsp_ctx* ctx, int B, int L, int hop);
+int vsp_spectrogram(vsp_ctx* ctx, void* stream, int B, int L, int hop, const float* audio, float* spec,
+                    void* workspace, int64_t workspace_bytes);
 /* 1 if the posterior-encoder weights are loaded (voice conversion available), else 0. */
 int vsp_has_voice_conversion(const vsp_ctx* ctx);
 

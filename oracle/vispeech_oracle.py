@@ -385,6 +385,19 @@ def _vc(self, y, y_lengths, sid_src, sid_tgt, noise):
 Oracle.voice_conversion = torch.no_grad()(_vc)
 
 
+def spectrogram(y, n_fft: int, hop: int):
+    """mel_processing.spectrogram_torch (reference mel_processing.py:50-69; win_size = n_fft, center=False):
+    reflect padding of (n_fft - hop)/2, periodic Hann window, one-sided STFT, sqrt(|X|^2 + 1e-6).  The
+    reference calls torch.stft without ``return_complex`` (rejected by torch >= 2.0), so this restatement
+    uses the complex form of the same routine: same arithmetic, parity unpinned by a reference RUN."""
+    y = torch.as_tensor(y, dtype=torch.float32)
+    pad = int((n_fft - hop) / 2)
+    yp = F.pad(y[:, None, :], (pad, pad), mode="reflect")[:, 0]
+    spec = torch.stft(yp, n_fft, hop_length=hop, win_length=n_fft, window=torch.hann_window(n_fft), center=False,
+                      normalized=False, onesided=True, return_complex=True)
+    return torch.sqrt(spec.real.pow(2) + spec.imag.pow(2) + 1e-6)
+
+
 def rq_spline(inputs, uw, uh, ud, inverse=False, tail_bound=5.0, min_bin_width=1e-3,
               min_bin_height=1e-3, min_derivative=1e-3):
     """Unconstrained (linear-tail) monotone rational-quadratic spline of reference

@@ -80,3 +80,22 @@ def test_oracle_voice_conversion_matches_reference(golden_dir):
     assert rel_err(out["o_hat"].numpy(), g["o_hat"]) <= 1e-4
     # same speaker on both sides: the two flow passes cancel (row 1 has sid_src == sid_tgt)
     assert np.abs(out["z_hat"][1].numpy() - out["z"][1].numpy()).max() <= 1e-4 * np.abs(g["z"][1]).max()
+
+
+def test_oracle_spectrogram_matches_direct_dft():
+    """oracle.spectrogram (torch.stft restatement of reference mel_processing.py:50-69) against a direct
+    float64 DFT of the reflect-padded, Hann-windowed frames."""
+    from oracle.vispeech_oracle import spectrogram
+    r = np.random.Generator(np.random.PCG64(1))
+    n_fft, hop, L = 64, 16, 16 * 9
+    y = r.uniform(-1, 1, (2, L)).astype(np.float32)
+    got = spectrogram(y, n_fft, hop).numpy()
+    pad = (n_fft - hop) // 2
+    yp = np.pad(y.astype(np.float64), ((0, 0), (pad, pad)), mode="reflect")
+    win = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n_fft) / n_fft)
+    T = 1 + (yp.shape[1] - n_fft) // hop
+    assert got.shape == (2, n_fft // 2 + 1, T) and T == L // hop
+    frames = np.stack([yp[:, t * hop:t * hop + n_fft] * win for t in range(T)], axis=2)      # [B, n_fft, T]
+    X = np.fft.rfft(frames, axis=1)
+    ref = np.sqrt(X.real ** 2 + X.imag ** 2 + 1e-6)
+    assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()

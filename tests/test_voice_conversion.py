@@ -121,3 +121,41 @@ def test_voice_conversion_needs_posterior_weights(dims):
     with pytest.raises(VspError, match="STATE"):
         m._engine.voice_conversion(y, torch.tensor([8]), torch.tensor([0]), torch.tensor([1]),
                                    torch.zeros(1, dims.inter_channels, 8))
+
+
+def test_spectrogram_front_end_matches_oracle(net, dims):
+    """vsp_spectrogram (DFT as a split-f16 MFMA conv over reflect-padded frames) against torch.stft in the
+    oracle: the linear spectrogram that voice_conversion consumes (reference mel_processing.py:50-69)."""
+    from oracle.vispeech_oracle import spectrogram
+    r = np.random.Generator(np.random.PCG64(3))
+    n_fft, hop = 2 * (dims.spec_channels - 1), dims.hop_length
+    for B, L in ((2, 512 * 37), (1, 4097), (3, 1000)):
+        t = np.arange(L) / dims.sampling_rate
+        audio = (0.4 * np.sin(2 * np.pi * 220.0 * t)[None, :] * r.uniform(0.2, 1.0, (B, 1)) +
+                 0.1 * r.standard_normal((B, L))).astype(np.float32).clip(-1, 1)
+        ref = spectrogram(audio, n_fft, hop).numpy()
+        got = to_np(net._engine.spectrogram(audio))
+        assert got.shape == ref.shape == (B, dims.spec_channels, 1 + (L + 2 * ((n_fft - hop) // 2) - n_fft) // hop)
+        assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max(), (B, L, np.abs(got - ref).max(), np.abs(ref).max())
+
+
+def test_wav_to_wav_voice_conversion(net, oracle, dims):
+    """Audio in, audio out: spectrogram front end + voice_conversion, against the oracle's torch.stft + VC."""
+    from oracle.vispeech_oracle import spectrogram
+    r = np.random.Generator(np.random.PCG64(9))
+    L = 512 * 24
+    audio = (0.3 * r.standard_normal((2, L))).astype(np.float32).clip(-1, 1)
+    n_fft = 2 * (dims.spec_channels - 1)
+    y_ref = spectrogram(audio, n_fft, dims.hop_length)
+    lens = np.array([24, 17], dtype=np.int64)
+    y_ref = y_ref * (torch.arange(24)[None, None, :] < torch.from_numpy(lens)[:, None, None])
+    noise = r.standard_normal((2, dims.inter_channels, 24)).astype(np.float32)
+    src, tgt = np.array([5, 6]), np.array([20, 6])
+    ref = oracle.voice_conversion(y_ref.numpy(), lens, src, tgt, noise)
+    y = net._engine.spectrogram(audio)
+    y = y * (torch.arange(24, device=y.device)[None, None, :] < torch.from_numpy(lens).to(y.device)[:, None, None])
+    dev = net.device
+    t = lambda x: torch.from_numpy(np.asarray(x)).to(dev)
+    o_hat, _, (z, z_p, z_hat) = net.voice_conversion(y, t(lens), t(src), t(tgt), noise=t(noise))
+    assert rel_err(to_np(z), ref["z"].numpy()) <= 5e-5            # spectrogram error rides on top of the stage error
+    assert rel_err(to_np(o_hat), ref["o_hat"].numpy()) <= 2e-4

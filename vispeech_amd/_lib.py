@@ -75,6 +75,9 @@ SIGNATURES = {
     "vsp_posterior_workspace_bytes": (_I64, [_P, _I, _I]),
     "vsp_posterior_encoder": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I64]),
     "vsp_has_voice_conversion": (_I, [_P]),
+    "vsp_spectrogram_frames": (_I, [_P, _I, _I]),
+    "vsp_spectrogram_workspace_bytes": (_I64, [_P, _I, _I, _I]),
+    "vsp_spectrogram": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _I64]),
     "vsp_rq_spline": (_I, [_P, _I64, _I, _P, _P, _P, _P, _I, _F, _P, _P]),
     "vsp_profile_enable": (_I, [_P, _I]),
     "vsp_profile_read": (_I, [_P, C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), _I]),

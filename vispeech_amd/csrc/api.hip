@@ -969,6 +969,51 @@ int vsp_flow_forward(vsp_ctx* ctx, void* stream, int B, int Tf, const float* z, 
   return r.rc;
 }
 
+// ---------------------------------------------------------------------------------- spectrogram
+int vsp_spectrogram_frames(const vsp_ctx* ctx, int L, int hop) {
+  if (!ctx || ctx->cfg.spec_channels <= 1 || hop <= 0) return VSP_ERR_ARG;
+  const int n_fft = 2 * (ctx->cfg.spec_channels - 1), pad = (n_fft - hop) / 2;
+  if (L <= pad || n_fft < hop) return VSP_ERR_ARG;      // reflect padding needs pad < L
+  return 1 + (L + 2 * pad - n_fft) / hop;
+}
+
+static int spectrogram_impl(vsp_ctx* ctx, hipStream_t s, Ws& ws, int B, int L, int hop, int T, const float* audio,
+                            float* spec) {
+  const vsp_config& c = ctx->cfg;
+  const int n_fft = 2 * (c.spec_channels - 1);
+  Run r{ctx, s, ws};
+  T3 F = ws.t3(B, n_fft, T), RI = ws.t3(B, 2 * c.spec_channels, T);
+  if (ws.dry) return VSP_OK;
+  if (ws.overflow) return ctx->fail(VSP_ERR_WORKSPACE, "spectrogram workspace too small");
+  r.chk(launch_stft_frames(audio, L, F.p, F.bs, F.cs, B, L, n_fft, hop, T, s), "stft frames");
+  ConvArgs a = r.args(ctx->model.stft, F, RI, T, T);
+  r.conv(a, B);
+  if (r.ok()) r.chk(launch_stft_magnitude(RI.p, RI.bs, RI.cs, spec, B, c.spec_channels, T, s), "stft magnitude");
+  return r.rc;
+}
+
+int64_t vsp_spectrogram_workspace_bytes(const vsp_ctx* ctx, int B, int L, int hop) {
+  const int T = vsp_spectrogram_frames(ctx, L, hop);
+  if (T <= 0 || B <= 0) return VSP_ERR_ARG;
+  Ws ws(nullptr, 0, true);
+  spectrogram_impl(const_cast<vsp_ctx*>(ctx), nullptr, ws, B, L, hop, T, nullptr, nullptr);
+  return (int64_t)ws.cur;
+}
+
+int vsp_spectrogram(vsp_ctx* ctx, void* stream, int B, int L, int hop, const float* audio, float* spec, void* workspace,
+                    int64_t workspace_bytes) {
+  int rc = check_ready(ctx);
+  if (rc) return rc;
+  if (ctx->cfg.spec_channels <= 1) return ctx->fail(VSP_ERR_STATE, "context was created without spec_channels");
+  const int T = vsp_spectrogram_frames(ctx, L, hop);
+  if (T <= 0 || B <= 0 || !audio || !spec || !workspace)
+    return ctx->fail(VSP_ERR_ARG, "vsp_spectrogram: bad argument (the signal must be longer than (n_fft - hop) / 2)");
+  if (workspace_bytes < vsp_spectrogram_workspace_bytes(ctx, B, L, hop))
+    return ctx->fail(VSP_ERR_WORKSPACE, "spectrogram workspace too small");
+  Ws ws(workspace, (size_t)workspace_bytes, false);
+  return spectrogram_impl(ctx, (hipStream_t)stream, ws, B, L, hop, T, audio, spec);
+}
+
 // ---------------------------------------------------------------------------------- voice conversion
 static int check_vc(vsp_ctx* ctx) {
   const int rc = check_ready(ctx);

@@ -142,4 +142,9 @@ hipError_t launch_rq_spline(int64_t n, int nb, const float* x, const float* uw, 
                             const float* ud, int inverse, float tail_bound, float* y, float* lad,
                             hipStream_t s);
 
+hipError_t launch_stft_frames(const float* audio, long a_bs, float* f, long f_bs, long f_cs, int B, int L, int n_fft,
+                              int hop, int T, hipStream_t s);
+hipError_t launch_stft_magnitude(const float* ri, long r_bs, long r_cs, float* spec, int B, int spec_ch, int T,
+                                 hipStream_t s);
+
 }  // namespace vsp

@@ -461,4 +461,39 @@ hipError_t launch_rq_spline(int64_t n, int nb, const float* x, const float* uw, 
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// spectrogram front end (reference mel_processing.py:50-69): frames of the reflect-padded signal as the
+// [n_fft][T] "channel x time" operand of the DFT conv, then the magnitude of the (re, im) rows.
+__global__ void stft_frames_kernel(const float* __restrict__ audio, long a_bs, float* __restrict__ f, long f_bs, long f_cs,
+                                   int L, int n_fft, int hop, int T) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y, b = blockIdx.z;
+  if (t >= T) return;
+  const int pad = (n_fft - hop) / 2;
+  int i = t * hop + n - pad;
+  if (i < 0) i = -i;                       // torch reflect padding (edge sample not repeated)
+  if (i >= L) i = 2 * (L - 1) - i;
+  f[(size_t)b * f_bs + (size_t)n * f_cs + t] = audio[(size_t)b * a_bs + i];
+}
+hipError_t launch_stft_frames(const float* audio, long a_bs, float* f, long f_bs, long f_cs, int B, int L, int n_fft,
+                              int hop, int T, hipStream_t s) {
+  hipLaunchKernelGGL(stft_frames_kernel, dim3((T + 255) / 256, n_fft, B), dim3(256), 0, s, audio, a_bs, f, f_bs, f_cs, L,
+                     n_fft, hop, T);
+  return hipGetLastError();
+}
+
+__global__ void stft_magnitude_kernel(const float* __restrict__ ri, long r_bs, long r_cs, float* __restrict__ spec,
+                                      int spec_ch, int T) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y, b = blockIdx.z;
+  if (t >= T) return;
+  const float re = ri[(size_t)b * r_bs + (size_t)r * r_cs + t];
+  const float im = ri[(size_t)b * r_bs + (size_t)(spec_ch + r) * r_cs + t];
+  spec[((size_t)b * spec_ch + r) * T + t] = sqrtf(re * re + im * im + 1e-6f);
+}
+hipError_t launch_stft_magnitude(const float* ri, long r_bs, long r_cs, float* spec, int B, int spec_ch, int T,
+                                 hipStream_t s) {
+  hipLaunchKernelGGL(stft_magnitude_kernel, dim3((T + 255) / 256, spec_ch, B), dim3(256), 0, s, ri, r_bs, r_cs, spec,
+                     spec_ch, T);
+  return hipGetLastError();
+}
+
 }  // namespace vsp

@@ -72,6 +72,7 @@ struct Model {
   size_t ppre_w = 0, ppre_b = 0, epre_w = 0, epre_b = 0;
   Conv proj_m, proj_s;
   std::vector<FlowW> flows;  // index = flow layer i (applied in order n_flows-1 .. 0)
+  Conv stft;            // windowed one-sided DFT basis (rows: cos 0..spec-1, then -sin), planned when cfg.spec_channels > 0
   PosteriorW enc_q;     // planned when cfg.spec_channels > 0
   bool has_vc = false;  // enc_q weights were packed (voice conversion available)
   Conv g_pre, g_cond;

@@ -268,6 +268,9 @@ int plan_model(vsp_ctx* ctx) {
     return ctx->fail(VSP_ERR_UNSUPPORTED, "odd n_flows leaves the latent channel-flipped; only even counts are folded");
   if (c.spec_channels > 0) {
     if (c.posterior_layers < 1) return ctx->fail(VSP_ERR_ARG, "posterior_layers < 1");
+    // spectrogram front end of voice conversion: DFT as a 1x1 conv over the n_fft samples of a frame
+    const int n_fft = 2 * (c.spec_channels - 1);
+    m.stft = p.conv(2 * c.spec_channels, n_fft, 1, 1, 0, false);
     PosteriorW& Q = m.enc_q;
     const int ql = c.posterior_layers;
     Q.pre = p.conv(h, c.spec_channels, 1, 1, 0, true);
@@ -558,6 +561,20 @@ int fill_model(vsp_ctx* ctx, std::vector<float>& arena) {
     }
   }
 
+  // windowed DFT basis of the spectrogram front end (config-derived, no checkpoint tensor): row r < spec is
+  // cos(2 pi r n / N) * hann[n], row spec + r is -sin(...) * hann[n]; periodic Hann (torch.hann_window)
+  if (c.spec_channels > 0 && f.ok) {
+    const int spec = c.spec_channels, N = 2 * (spec - 1);
+    std::vector<double> hann(N);
+    for (int n = 0; n < N; ++n) hann[n] = 0.5 - 0.5 * std::cos(2.0 * M_PI * n / N);
+    std::vector<double> cs(N), sn(N);
+    for (int k = 0; k < N; ++k) { cs[k] = std::cos(2.0 * M_PI * k / N); sn[k] = std::sin(2.0 * M_PI * k / N); }
+    f.conv(m.stft, [&](int row, int n, int) {
+      const int r = row < spec ? row : row - spec;
+      const int k = (int)(((long long)r * n) % N);        // exact angle reduction
+      return (float)((row < spec ? cs[k] : -sn[k]) * hann[n]);
+    }, [](int) { return 0.f; });
+  }
   // posterior encoder (optional): packed only when every enc_q tensor was supplied
   m.has_vc = false;
   if (c.spec_channels > 0 && f.ok) {

@@ -274,6 +274,24 @@ class Engine:
     def has_voice_conversion(self) -> bool:
         return bool(self.lib.vsp_has_voice_conversion(self.ctx))
 
+    def spectrogram(self, audio, hop_length: Optional[int] = None) -> torch.Tensor:
+        """``mel_processing.spectrogram_torch`` (reference mel_processing.py:50-69): audio [B, L] in [-1, 1] ->
+        linear magnitude spectrogram [B, spec_channels, L // hop] (n_fft = win = 2 * (spec_channels - 1))."""
+        a = _dev_f32(audio, self.device)
+        if a.dim() != 2:
+            raise ValueError("audio must be [B, L]")
+        hop = int(self.dims.hop_length if hop_length is None else hop_length)
+        B, L = a.shape
+        T = int(self.lib.vsp_spectrogram_frames(self.ctx, L, hop))
+        if T <= 0:
+            raise ValueError("signal too short for the reflect padding of the spectrogram")
+        spec = self._f(B, self.dims.spec_channels, T)
+        ws = self._workspace("spectrogram", self.lib.vsp_spectrogram_workspace_bytes(self.ctx, B, L, hop))
+        with torch.cuda.device(self.device):
+            rc = self.lib.vsp_spectrogram(self.ctx, self._stream(), B, L, hop, _ptr(a), _ptr(spec), _ptr(ws), ws.numel())
+        _lib.check(rc, self.ctx, "vsp_spectrogram")
+        return spec
+
     def posterior_encoder(self, y, y_lengths, g, noise):
         """PosteriorEncoder.forward (reference models.py:233-241) -> (z, m, logs)."""
         y = _dev_f32(y, self.device)
