@@ -1,7 +1,8 @@
 """ORACLE -- test infrastructure, not product code.
 
 CPU (torch fp32/fp64, functional) restatement of the reference's
-``SynthesizerTrn.infer`` hot path and of its rational-quadratic spline.  Only
+``SynthesizerTrn.infer`` hot path, of ``voice_conversion`` (posterior encoder +
+forward flow), of its rational-quadratic spline and of the linear spectrogram.  Only
 ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
 leg may import this package; ``vispeech_amd`` never does.
 
@@ -10,7 +11,10 @@ Pinning: the reference ships no tests or golden vectors for this path
 real reference (imported from /root/reference in the build container by
 ``tests/golden/make_golden.py``) on seeded synthetic weights and inputs;
 ``tests/test_oracle_golden.py`` checks this restatement against every stored
-stage boundary.
+stage boundary (infer: 4 cases, voice_conversion: 1, spline: 1).  ``spectrogram``
+is the exception: the reference's ``torch.stft`` call form is rejected by the
+installed torch, so that function is pinned against a float64 DFT, not against a
+reference run (parity unpinned in the task's sense).
 
 It is written independently of the reference's module classes: weight-norm is
 folded once, relative-position attention uses the closed banded form instead of
