@@ -402,6 +402,41 @@ def spectrogram(y, n_fft: int, hop: int):
     return torch.sqrt(spec.real.pow(2) + spec.imag.pow(2) + 1e-6)
 
 
+def mel_filterbank(sr: int, n_fft: int, n_mels: int, fmin: float = 0.0, fmax: Optional[float] = None) -> np.ndarray:
+    """The Slaney-style mel filterbank that ``librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax)`` returns with
+    its defaults (htk=False, norm='slaney'), which reference mel_processing.py:79 calls.  librosa is not in this
+    image and the reference pins no version: this restates the published algorithm (linear below 1 kHz at
+    200/3 Hz per mel, log above with step ln(6.4)/27; triangles between successive mel points; area
+    normalisation 2 / (f[m+2] - f[m])).  Parity unpinned; used only as an audio-domain metric in tests."""
+    fmax = sr / 2.0 if fmax is None else fmax
+    f_sp, min_log_hz = 200.0 / 3.0, 1000.0
+    min_log_mel, logstep = min_log_hz / f_sp, np.log(6.4) / 27.0
+
+    def hz_to_mel(f):
+        f = np.asarray(f, dtype=np.float64)
+        return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-30) / min_log_hz) / logstep, f / f_sp)
+
+    def mel_to_hz(m):
+        m = np.asarray(m, dtype=np.float64)
+        return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+    fft_f = np.linspace(0.0, sr / 2.0, n_fft // 2 + 1)
+    mel_f = mel_to_hz(np.linspace(hz_to_mel(fmin), hz_to_mel(fmax), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = mel_f[:, None] - fft_f[None, :]
+    w = np.maximum(0.0, np.minimum(-ramps[:-2] / fdiff[:-1, None], ramps[2:] / fdiff[1:, None]))
+    w *= (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]
+    return w.astype(np.float32)
+
+
+def mel_spectrogram(y, sr: int, n_fft: int, hop: int, n_mels: int, fmin: float = 0.0, fmax: Optional[float] = None):
+    """mel_processing.mel_spectrogram_torch (reference mel_processing.py:85-112): spectrogram -> mel basis ->
+    log(clamp(x, 1e-5)) (dynamic range compression, mel_processing.py:16-22, 35-37)."""
+    spec = spectrogram(y, n_fft, hop)
+    mel = torch.from_numpy(mel_filterbank(sr, n_fft, n_mels, fmin, fmax)) @ spec
+    return torch.log(torch.clamp(mel, min=1e-5))
+
+
 def rq_spline(inputs, uw, uh, ud, inverse=False, tail_bound=5.0, min_bin_width=1e-3,
               min_bin_height=1e-3, min_derivative=1e-3):
     """Unconstrained (linear-tail) monotone rational-quadratic spline of reference

@@ -99,3 +99,22 @@ def test_oracle_spectrogram_matches_direct_dft():
     X = np.fft.rfft(frames, axis=1)
     ref = np.sqrt(X.real ** 2 + X.imag ** 2 + 1e-6)
     assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
+def test_oracle_mel_filterbank_properties():
+    """Slaney mel filterbank restated from librosa's published algorithm: shape, non-negativity, triangles that
+    cover the band with area normalisation (each filter integrates to ~1 Hz^-1 * Hz), monotone centre frequencies."""
+    from oracle.vispeech_oracle import mel_filterbank, mel_spectrogram
+    fb = mel_filterbank(44100, 2048, 80)
+    assert fb.shape == (80, 1025) and fb.min() >= 0.0
+    centres = fb.argmax(axis=1)
+    assert np.all(np.diff(centres) > 0)
+    df = 44100 / 2048
+    area = fb.sum(axis=1) * df
+    assert np.allclose(area[5:], 1.0, atol=0.05)           # slaney norm: unit area once a triangle spans several bins
+    lin = fb[:10].argmax(axis=1) * df                        # below 1 kHz the centres are 200/3 Hz * k apart (+ grid rounding)
+    assert np.all(np.abs(np.diff(lin) - np.diff(lin).mean()) <= df)
+    y = np.sin(2 * np.pi * 440.0 * np.arange(8192) / 44100.0)[None, :].astype(np.float32) * 0.5
+    m = mel_spectrogram(y, 44100, 2048, 512, 80).numpy()
+    assert m.shape == (1, 80, 16) and np.isfinite(m).all()
+    assert abs(int(m[0, :, 8].argmax()) - int(np.abs(fb[:, round(440.0 / df)]).argmax())) <= 1
