@@ -77,10 +77,10 @@ void pack_cl_weights(uint16_t* hi, uint16_t* lo, int Cout, int Cin, int K, int p
 
 // Block = 8 waves, 256 time rows x (NT*WN*32) output channels.  Per ci-chunk the activated, split
 // input window sits in LDS (one buffer); the weights stream through a double-buffered LDS ring in
-// slices of G taps x one chunk (32 KiB hi+lo), fetched from L2 ONCE per block (register-staged one
-// slice ahead, so the fetch latency hides under the MFMAs of the current slice).  Every wave then
-// reads both operands' fragments from LDS (ds_read_b128, conflict-free) one k-step ahead of the
-// MFMAs that consume them.
+// slices of G taps x one chunk (32 KiB hi+lo), fetched from L2 ONCE per block, one slice ahead: by
+// LDS-DMA on the 128-column tile (GLDS), through staging registers on the small tiles.  Every wave then
+// reads both operands' fragments from LDS (ds_read_b128, conflict-free); where registers allow (PF) the
+// fragments of the next k-step are requested before the MFMAs of the current one.
 //
 // Addressing: rocprofv3 --pmc showed the first versions issuing 18-57 VALU instructions per MFMA,
 // nearly all 64-bit index arithmetic and per-element bounds branches (the epilogue alone was ~1100
@@ -566,11 +566,12 @@ hipError_t launch_cl_conv(const ClConvArgs& a, int B, hipStream_t s) {
   if ((a.K - 1) * a.dil > CL_HALO || a.K < 1 || a.Nq <= 0 || B <= 0 || a.Cout % 32 || a.Cin % 32 || a.phases < 1 ||
       (a.x_ts & 3) || (a.x_bs & 3) || (reinterpret_cast<uintptr_t>(a.x) & 15))
     return hipErrorInvalidValue;
-  // <MT, NT, WM, WN, CKC, G, PF>; tile choices measured on MI355X (profiles/r01_tile_experiments.txt):
+  // <MT, NT, WM, WN, CKC, G, PF, WD, TERMS, GLDS>; tile choices measured on MI355X (profiles/r01_tile_experiments.txt):
   //  * >= 128 output channels: 8 waves x (64 rows x 64 channels), 64-channel chunks, one block per CU
-  //    (2 blocks of 4 waves, or fragment prefetch at 256 VGPRs, were both slower);
+  //    (two blocks of 4 waves, one fat wave per SIMD, 64-column tiles at two blocks per CU: all measured slower or equal);
   //  * 64 / 32 output channels: LDS kept under 80 KiB (32-channel chunks, small weight ring) so that
-  //    TWO blocks share a CU and overlap each other's load / MFMA / store phases.
+  //    TWO blocks share a CU.  With the ResBlock pairs of those stages fused (respair_f16s.hip) only the
+  //    transposed convs into them still use these two tiles.
   if (a.terms == 1) {
     if (a.Cout % 128 == 0 && a.Cin % 64 == 0) return launch_cl_tile<2, 2, 4, 2, 64, 1, false, 2, 1>(a, B, s);
     if (a.Cout % 64 == 0) return launch_cl_tile<2, 1, 4, 2, 32, 1, true, 1, 1>(a, B, s);
