@@ -131,11 +131,18 @@ __global__ void __launch_bounds__(64 * WM * WN) cl_conv_f16s(ClConvArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
-  const int b = blockIdx.z;
-  const int t0 = blockIdx.x * BT;
   const int nnt = a.Cout >> 5, nks = a.Cin >> 4;
   const int ncb = nnt / NTB;
-  const int ph = blockIdx.y / ncb, cb = blockIdx.y - ph * ncb;
+  // XCD-aware block numbering (workgroup ids go round-robin over the 8 XCDs): XCD k gets the k-th contiguous eighth
+  // of the sequence (utterance, time tile, column group / phase), column group fastest -- the blocks that read the
+  // same input window (all column groups of a time tile) and the neighbouring tiles (shared halo) share an L2
+  const int gy = gridDim.y, gx = gridDim.x;
+  const int nwg = gx * gy * gridDim.z, orig = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+  const int xcd = orig & 7, qd = nwg >> 3, rem = nwg & 7;
+  const int id = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (orig >> 3);
+  const int by = id % gy, bx = (id / gy) % gx, b = id / (gy * gx);
+  const int t0 = bx * BT;
+  const int ph = by / ncb, cb = by - ph * ncb;
   const int row0 = wm * MT * 32;
   const int nchunks = a.Cin / CKC;
   const int ns = (a.K + G - 1) / G;           // weight slices per chunk
