@@ -77,6 +77,7 @@ __global__ void __launch_bounds__(512 / MT, 4 / MT) cl_respair_f16s(ClPairArgs a
   constexpr int NBLK = (TERMS == 3 ? 2 : 1) * G * KS * NT;
   constexpr int NWL = (NBLK + NWV - 1) / NWV;
   constexpr int NCH = NT;                        // 32-channel chunks of the contraction
+  constexpr bool EARLY_RES = NT == 1 && MT == 1 && TERMS == 3;
   extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
   // [rows][RS] hi, then lo: x window, later the t image; the weight ring before (XW) or after it
   _Float16* const Xh = XW ? lds + 4 * WIMG : lds;
@@ -285,7 +286,8 @@ __global__ void __launch_bounds__(512 / MT, 4 / MT) cl_respair_f16s(ClPairArgs a
     const _Float16* Wc = Wb + (step & 1) * 2 * WIMG;
     const int tap0 = sl * G;
     const int nit = ((K - tap0) < G ? (K - tap0) : G) * KS;
-    if constexpr (PF && (NT == 1 || MT == 2) && (G * KS) % 4 == 0) {
+    // (the 32-channel 8-wave tile spends its spare registers on the early residual rows instead: EARLY_RES)
+    if constexpr (!EARLY_RES && PF && (NT == 1 || MT == 2) && (G * KS) % 4 == 0) {
       // registers to spare: the fragments of four k-steps (two taps) are requested before the first of their
       // MFMAs (one LDS round trip per four k-steps instead of one per k-step: 3 MFMAs do not cover it)
       f16x8 xhC[MT], xlC[MT], whC[NT], wlC[NT], xhD[MT], xlD[MT], whD[NT], wlD[NT];
@@ -325,6 +327,21 @@ __global__ void __launch_bounds__(512 / MT, 4 / MT) cl_respair_f16s(ClPairArgs a
 
   // ================= conv1 =================
   init_acc(a.b1);
+  // EARLY_RES: the residual rows are requested together with the window -- same lines at the same time, so the
+  // second request hits L2; 20 us later (epilogue) they had been evicted and cost a second HBM pass (PMC: 1.7-1.9
+  // fetch passes per pair before, measured -0.85 ms per step)
+  [[maybe_unused]] float rv_early[16];
+  if constexpr (EARLY_RES) {
+    const int R2e = RP_BT - (a.K - 1);
+    const int loe = (tile * R2e + row0 + 4 * h) * (C * 4) + l31 * 4;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rr = (r & 3) + 8 * (r >> 2);
+      rv_early[r] = (VSP_DIAG & 8) ? 1.f
+                                    : __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                                          rx, (row0 + 4 * h + rr) < R2e ? loe + rr * C * 4 : 0x7ffffff0, 0, 0));
+    }
+  }
   x_issue(0);
   w_issue(0, 0, 0, 0);
   RP_STAMP();                                   // 1: loads issued
@@ -451,8 +468,10 @@ __global__ void __launch_bounds__(512 / MT, 4 / MT) cl_respair_f16s(ClPairArgs a
     }
     float v[16], rv[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-      rv[r] = (VSP_DIAG & 8) ? 1.f : __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, off[r], 0, 0));
+    for (int r = 0; r < 16; ++r) {
+      if constexpr (EARLY_RES) rv[r] = rv_early[r];
+      else rv[r] = (VSP_DIAG & 8) ? 1.f : __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, off[r], 0, 0));
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r)
       v[r] = (TERMS == 3 ? hh[mt][nt][r] + cr[mt][nt][r] * (1.f / 2048.f) : hh[mt][nt][r]) + rv[r];
