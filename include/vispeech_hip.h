@@ -219,14 +219,30 @@ int vsp_rq_spline(void* stream, int64_t n, int nb, const float* x, const float* 
                   const float* ud, int inverse, float tail_bound, float* y, float* logabsdet);
 
 /* ---- measurement -------------------------------------------------------------------------- */
-/* When enabled, every launch of the dominant kernel (the generator's MFMA convolution) is
- * bracketed by a HIP event pair on the launch stream.  vsp_profile_read synchronises those events
- * and returns, since the last reset: the number of launches, their summed duration in
- * milliseconds, their summed algorithmic FLOPs (2 * Cout * Cin * taps * columns * B) and their
- * summed algorithmic bytes (input once + output once + residual / accumulate reads, fp32). */
+/* When enabled, every launch of a profiled class is bracketed by a HIP event pair on the launch
+ * stream.  vsp_profile_read_class synchronises those events and returns, since the last reset, for
+ * one class: the number of launches, their summed duration in milliseconds, their summed
+ * algorithmic FLOPs and their summed algorithmic bytes:
+ *   VSP_PROF_GENERATOR  the generator's convolutions (conv_pre, ups, ResBlock convs / fused pairs):
+ *                       FLOPs 2 * Cout * Cin * taps * columns * B; bytes = SURVEY.md 8d's
+ *                       layer-boundary model, input once + output once per convolution, fp32 (a fused
+ *                       pair is charged the two convolutions it replaces = 4 passes); bytes_ext adds
+ *                       the residual / accumulate operand reads (5-6 passes per pair);
+ *   VSP_PROF_ATTENTION  relative-position attention launches (reference attentions.py:148-179):
+ *                       FLOPs 4 * H * T^2 (QK^T and PV) + 4 * H * T * (2 window + 1) (banded
+ *                       relative terms) per utterance; bytes = q|k|v in + out;
+ *   VSP_PROF_FRAME      every other conv1d launch (encoders, predictors, flow, projection).
+ * Profiling costs two hipEventRecord per launch: time the headline with it OFF.
+ * vsp_profile_read is the class VSP_PROF_GENERATOR (kept from ABI version 2). */
+#define VSP_PROF_GENERATOR 0
+#define VSP_PROF_ATTENTION 1
+#define VSP_PROF_FRAME 2
+#define VSP_PROF_CLASSES 3
 int vsp_profile_enable(vsp_ctx* ctx, int on);
 int vsp_profile_read(vsp_ctx* ctx, int64_t* launches, double* total_ms, double* total_flops, double* total_bytes,
                      int reset);
+int vsp_profile_read_class(vsp_ctx* ctx, int cls, int64_t* launches, double* total_ms, double* total_flops,
+                           double* total_bytes, double* total_bytes_ext, int reset);
 
 #ifdef __cplusplus
 }

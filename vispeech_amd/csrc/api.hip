@@ -74,26 +74,36 @@ struct Run {
     a.f16s = L.f16s ? 1 : 0;
     return a;
   }
-  void conv(const ConvArgs& a, int B, bool profile = false) {
-    if (dry() || !ok()) return;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (profile && ctx->prof_on) {
-      while (ctx->ev_pool.size() < ctx->ev_used + 2) {
-        hipEvent_t e;
-        if (hipEventCreate(&e) != hipSuccess) { rc = ctx->fail(VSP_ERR_HIP, "hipEventCreate"); return; }
-        ctx->ev_pool.push_back(e);
-      }
-      e0 = ctx->ev_pool[ctx->ev_used++];
-      e1 = ctx->ev_pool[ctx->ev_used++];
-      (void)hipEventRecord(e0, s);
+  // event pair around one launch of a profiled class; end() books the launch's algorithmic work
+  bool prof_begin(int cls) {
+    if (!ctx->prof_on) return false;
+    while (ctx->ev_pool.size() < ctx->ev_used + 2) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) { rc = ctx->fail(VSP_ERR_HIP, "hipEventCreate"); return false; }
+      ctx->ev_pool.push_back(e);
     }
+    if (ctx->ev_cls.size() < ctx->ev_pool.size() / 2) ctx->ev_cls.resize(ctx->ev_pool.size() / 2, 0);
+    ctx->ev_cls[ctx->ev_used / 2] = cls;
+    (void)hipEventRecord(ctx->ev_pool[ctx->ev_used], s);
+    return true;
+  }
+  void prof_end(int cls, double flops, double bytes, double bytes_ext) {
+    (void)hipEventRecord(ctx->ev_pool[ctx->ev_used + 1], s);
+    ctx->ev_used += 2;
+    ctx->prof_launches[cls] += 1;
+    ctx->prof_flops[cls] += flops;
+    ctx->prof_bytes[cls] += bytes;
+    ctx->prof_bytes_ext[cls] += bytes_ext;
+  }
+  void conv(const ConvArgs& a, int B, bool generator = false) {
+    if (dry() || !ok()) return;
+    const int cls = generator ? VSP_PROF_GENERATOR : VSP_PROF_FRAME;
+    const bool prof = prof_begin(cls);
     chk(launch_conv(a, B, s), "conv1d_f32_mfma");
-    if (e1) {
-      (void)hipEventRecord(e1, s);
-      ctx->prof_launches += 1;
-      ctx->prof_flops += 2.0 * a.M * a.Cin * a.K * (double)a.Nq * B;
+    if (prof) {
       const double in_el = (double)a.T_in * a.Cin, out_el = (double)(a.ups_s > 0 ? a.T_store * (a.M / a.ups_s) : a.Nq * a.M);
-      ctx->prof_bytes += 4.0 * B * (in_el + out_el * (1.0 + (a.res ? 1.0 : 0.0) + (a.acc_prev ? 1.0 : 0.0)));
+      prof_end(cls, 2.0 * a.M * a.Cin * a.K * (double)a.Nq * B, 4.0 * B * (in_el + out_el),
+               4.0 * B * (in_el + out_el * (1.0 + (a.res ? 1.0 : 0.0) + (a.acc_prev ? 1.0 : 0.0))));
     }
   }
   // channels-last split-f16 conv: x [B][T_in][Cin] -> out rows of Cout
@@ -103,7 +113,8 @@ struct Run {
     ClConvArgs a;
     std::memset(&a, 0, sizeof a);
     a.x = x; a.x_bs = x_bs; a.x_ts = L.Cin;
-    a.wh = reinterpret_cast<const uint16_t*>(A(L.wh));
+    const bool g16 = ctx->gen16;
+    a.wh = reinterpret_cast<const uint16_t*>(A(g16 ? L.wg : L.wh));
     a.wl = reinterpret_cast<const uint16_t*>(A(L.wl));
     a.bias = A((size_t)L.b);
     a.out = out; a.o_bs = o_bs; a.o_ts = L.Cout;
@@ -114,25 +125,14 @@ struct Run {
     a.acc_prev = acc_prev ? 1 : 0; a.div = div;
     a.phases = L.phases; a.ups_p = L.ups_p; a.T_store = T_store;
     a.terms = ctx->gen_mode == 2 ? 1 : 3;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (ctx->prof_on) {
-      while (ctx->ev_pool.size() < ctx->ev_used + 2) {
-        hipEvent_t e;
-        if (hipEventCreate(&e) != hipSuccess) { rc = ctx->fail(VSP_ERR_HIP, "hipEventCreate"); return; }
-        ctx->ev_pool.push_back(e);
-      }
-      e0 = ctx->ev_pool[ctx->ev_used++];
-      e1 = ctx->ev_pool[ctx->ev_used++];
-      (void)hipEventRecord(e0, s);
-    }
-    chk(launch_cl_conv(a, B, s), "cl_conv_f16s");
-    if (e1) {
-      (void)hipEventRecord(e1, s);
-      ctx->prof_launches += 1;
-      ctx->prof_flops += 2.0 * L.Cout * L.Cin * L.K * L.phases * (double)Nq * B;
-      // algorithmic bytes: input once, output once, plus the residual / accumulate reads
+    const bool prof = prof_begin(VSP_PROF_GENERATOR);
+    if (g16) chk(launch_g16_conv(a, B, s), "g16_conv");
+    else chk(launch_cl_conv(a, B, s), "cl_conv_f16s");
+    if (prof) {
+      // input once + output once; the residual / accumulate reads go to bytes_ext
       const double in_el = (double)T_in * L.Cin, out_el = (double)T_store * L.Cout;
-      ctx->prof_bytes += 4.0 * B * (in_el + out_el * (1.0 + (res ? 1.0 : 0.0) + (acc_prev ? 1.0 : 0.0)));
+      prof_end(VSP_PROF_GENERATOR, 2.0 * L.Cout * L.Cin * L.K * L.phases * (double)Nq * B, 4.0 * B * (in_el + out_el),
+               4.0 * B * (in_el + out_el * (1.0 + (res ? 1.0 : 0.0) + (acc_prev ? 1.0 : 0.0))));
     }
   }
   // fused ResBlock1 pair (respair_f16s.hip): out = x + conv2(lrelu(conv1(lrelu(x)))) [+ out] [/ div]
@@ -142,33 +142,23 @@ struct Run {
     ClPairArgs a;
     std::memset(&a, 0, sizeof a);
     a.x = x; a.x_bs = bs; a.out = out; a.o_bs = bs;
-    a.w1h = reinterpret_cast<const uint16_t*>(A(L1.wh)); a.w1l = reinterpret_cast<const uint16_t*>(A(L1.wl));
-    a.w2h = reinterpret_cast<const uint16_t*>(A(L2.wh)); a.w2l = reinterpret_cast<const uint16_t*>(A(L2.wl));
+    const bool g16 = ctx->gen16;
+    a.w1h = reinterpret_cast<const uint16_t*>(A(g16 ? L1.wg : L1.wh)); a.w1l = reinterpret_cast<const uint16_t*>(A(L1.wl));
+    a.w2h = reinterpret_cast<const uint16_t*>(A(g16 ? L2.wg : L2.wh)); a.w2l = reinterpret_cast<const uint16_t*>(A(L2.wl));
     a.b1 = A((size_t)L1.b); a.b2 = A((size_t)L2.b);
     a.C = L1.Cout; a.K = L1.K; a.dil = L1.dil; a.T = T;
     a.slope = 0.1f;                                    // modules.LRELU_SLOPE (reference modules.py:17)
     a.acc_prev = acc_prev ? 1 : 0; a.div = div;
     a.terms = ctx->gen_mode == 2 ? 1 : 3;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (ctx->prof_on) {
-      while (ctx->ev_pool.size() < ctx->ev_used + 2) {
-        hipEvent_t e;
-        if (hipEventCreate(&e) != hipSuccess) { rc = ctx->fail(VSP_ERR_HIP, "hipEventCreate"); return; }
-        ctx->ev_pool.push_back(e);
-      }
-      e0 = ctx->ev_pool[ctx->ev_used++];
-      e1 = ctx->ev_pool[ctx->ev_used++];
-      (void)hipEventRecord(e0, s);
-    }
-    chk(launch_cl_pair(a, B, s), "cl_respair_f16s");
-    if (e1) {
-      (void)hipEventRecord(e1, s);
-      ctx->prof_launches += 1;
-      ctx->prof_flops += 2.0 * 2.0 * L1.Cout * L1.Cin * L1.K * (double)T * B;
-      // algorithmic (layer-boundary) bytes of the two convs this launch replaces: conv1 in + out,
-      // conv2 in + out + residual (+ accumulate) -- SURVEY.md section 8d's traffic model
+    const bool prof = prof_begin(VSP_PROF_GENERATOR);
+    if (g16) chk(launch_g16_pair(a, B, s), "g16_pair");
+    else chk(launch_cl_pair(a, B, s), "cl_respair_f16s");
+    if (prof) {
+      // the two convolutions this launch replaces: SURVEY.md 8d charges each its input and its output (4 passes of
+      // T x C); with conv2's residual read (and the accumulate read of a ResBlock's last pair): 5 (6) -> bytes_ext
       const double el = (double)T * L1.Cout;
-      ctx->prof_bytes += 4.0 * B * el * (5.0 + (acc_prev ? 1.0 : 0.0));
+      prof_end(VSP_PROF_GENERATOR, 2.0 * 2.0 * L1.Cout * L1.Cin * L1.K * (double)T * B, 4.0 * B * el * 4.0,
+               4.0 * B * el * (5.0 + (acc_prev ? 1.0 : 0.0)));
     }
   }
   // cond(g): 1x1 conv on g [B][gin] (T = 1) -> out [B][M]
@@ -201,9 +191,14 @@ void run_encoder(Run& r, const EncoderW& E, int B, int T, T3 x_in, const int64_t
     ConvArgs a = r.args(L.qkv, X, QKV, T, T);
     a.lengths = lengths; a.in_mask = 1;  // x * x_mask feeds the attention (attentions.py:38)
     r.conv(a, B);
-    if (!r.dry() && r.ok())
+    if (!r.dry() && r.ok()) {
+      const bool prof = r.prof_begin(VSP_PROF_ATTENTION);
       r.chk(launch_attention(QKV.p, QKV.bs, QKV.cs, r.A(L.ek), r.A(L.ev), lengths, AT.p, AT.bs, AT.cs, B, h,
                              c.n_heads, T, c.window_size, r.ctx->att_ksplit, r.s), "attention");
+      // QK^T and PV: 2 * h * T^2 MAC per utterance; banded relative logits and values: 2 * h * T * (2w+1) MAC
+      if (prof) r.prof_end(VSP_PROF_ATTENTION, (double)B * (4.0 * h * (double)T * T + 4.0 * h * (double)T * (2 * c.window_size + 1)),
+                           4.0 * B * 4.0 * h * (double)T, 4.0 * B * 4.0 * h * (double)T);
+    }
     // S = (x*mask for layer 0 | x) + conv_o(att)
     a = r.args(L.o, AT, S, T, T);
     a.res = X.p; a.r_bs = X.bs; a.r_cs = X.cs;
@@ -455,7 +450,8 @@ void run_generator_cl(Run& r, int B, int T, T3 z, const int64_t* in_lengths, con
         const ResBlockW& rb = m.rbs[i * nk + j];
         const int nd = (int)rb.dil.size();
         bool fuse = r.ctx->fuse_pairs;
-        for (int d = 0; d < nd; ++d) fuse = fuse && cl_pair_supported(ch, rb.k, rb.dil[d]);
+        for (int d = 0; d < nd; ++d)
+          fuse = fuse && (r.ctx->gen16 ? g16_pair_supported(ch, rb.k, rb.dil[d]) : cl_pair_supported(ch, rb.k, rb.dil[d]));
         for (int d = 0; d < nd; ++d) {
           const bool last = d == nd - 1;
           const float div = (last && j == nk - 1) ? (float)nk : 1.f;
@@ -522,6 +518,7 @@ int vsp_create(const vsp_config* cfg, int device, vsp_ctx** out) {
   }
   if (const char* e = getenv("VSP_CHUNK_MB")) ctx->chunk_mb = atof(e);
   if (const char* e = getenv("VSP_FUSE_PAIRS")) ctx->fuse_pairs = atoi(e) != 0;
+  if (const char* e = getenv("VSP_GEN16")) ctx->gen16 = atoi(e) != 0;
   *out = ctx;  // returned even on failure so that vsp_last_error can be read; caller destroys it
   return rc;
 }
@@ -1150,32 +1147,53 @@ int vsp_rq_spline(void* stream, int64_t n, int nb, const float* x, const float* 
 // -------------------------------------------------------------------------------------------- profiling
 int vsp_profile_enable(vsp_ctx* ctx, int on) {
   if (!ctx) return VSP_ERR_ARG;
+  if (on && !ctx->prof_on) {          // a fresh measurement: forget whatever an earlier one left unread
+    ctx->ev_used = 0;
+    for (int c = 0; c < VSP_PROF_CLASSES; ++c) {
+      ctx->prof_launches[c] = 0;
+      ctx->prof_flops[c] = ctx->prof_bytes[c] = ctx->prof_bytes_ext[c] = 0.0;
+    }
+  }
   ctx->prof_on = on != 0;
   return VSP_OK;
 }
 
-int vsp_profile_read(vsp_ctx* ctx, int64_t* launches, double* total_ms, double* total_flops, double* total_bytes,
-                     int reset) {
-  if (!ctx || !launches || !total_ms || !total_flops || !total_bytes) return VSP_ERR_ARG;
+int vsp_profile_read_class(vsp_ctx* ctx, int cls, int64_t* launches, double* total_ms, double* total_flops,
+                           double* total_bytes, double* total_bytes_ext, int reset) {
+  if (!ctx || cls < 0 || cls >= VSP_PROF_CLASSES || !launches || !total_ms || !total_flops || !total_bytes)
+    return ctx ? ctx->fail(VSP_ERR_ARG, "vsp_profile_read_class: bad argument") : VSP_ERR_ARG;
   double ms = 0.0;
   for (size_t i = 0; i + 1 < ctx->ev_used; i += 2) {
+    if (ctx->ev_cls[i / 2] != cls) continue;
     hipError_t e = hipEventSynchronize(ctx->ev_pool[i + 1]);
     float t = 0.f;
     if (e == hipSuccess) e = hipEventElapsedTime(&t, ctx->ev_pool[i], ctx->ev_pool[i + 1]);
     if (e != hipSuccess) return ctx->fail(VSP_ERR_HIP, "profile events: %s", hipGetErrorString(e));
     ms += t;
   }
-  *launches = ctx->prof_launches;
+  *launches = ctx->prof_launches[cls];
   *total_ms = ms;
-  *total_flops = ctx->prof_flops;
-  *total_bytes = ctx->prof_bytes;
+  *total_flops = ctx->prof_flops[cls];
+  *total_bytes = ctx->prof_bytes[cls];
+  if (total_bytes_ext) *total_bytes_ext = ctx->prof_bytes_ext[cls];
   if (reset) {
-    ctx->ev_used = 0;
-    ctx->prof_launches = 0;
-    ctx->prof_flops = 0.0;
-    ctx->prof_bytes = 0.0;
+    // the event pool is shared: drop every class's events only when the LAST class has been read; a reset of one
+    // class zeroes its counters and marks its pairs as consumed
+    ctx->prof_launches[cls] = 0;
+    ctx->prof_flops[cls] = ctx->prof_bytes[cls] = ctx->prof_bytes_ext[cls] = 0.0;
+    bool any = false;
+    for (size_t i = 0; i + 1 < ctx->ev_used; i += 2) {
+      if (ctx->ev_cls[i / 2] == cls) ctx->ev_cls[i / 2] = -1;
+      else if (ctx->ev_cls[i / 2] >= 0) any = true;
+    }
+    if (!any) ctx->ev_used = 0;
   }
   return VSP_OK;
+}
+
+int vsp_profile_read(vsp_ctx* ctx, int64_t* launches, double* total_ms, double* total_flops, double* total_bytes,
+                     int reset) {
+  return vsp_profile_read_class(ctx, VSP_PROF_GENERATOR, launches, total_ms, total_flops, total_bytes, nullptr, reset);
 }
 
 }  // extern "C"

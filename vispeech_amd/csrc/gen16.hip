@@ -1,0 +1,632 @@
+// Vocoder convolutions on v_mfma_f32_16x16x32_f16 with SPLIT operands (fp32-accurate; conv_f16s.hip has the
+// arithmetic: x = xh + xl * 2^-11, three MFMAs per product into two accumulators HH / CROSS).
+//
+// Why a second generation of these kernels (round 2):
+//   * MFMA shape.  Under the chip's power cap the 16x16x32 form sustains 1.15x the FLOP/s of 32x32x16 on
+//     pseudo-random operands at identical LDS traffic (tools/micro/mfma_shape.hip, MI355X: 1976 vs 1717 TFLOP/s
+//     free-running, 1844 vs 1626 with a barrier per 64-deep step).
+//   * Orientation.  GEMM M = output channel (A = weights), N = time (B = activations), so a lane of a 16x16 D tile
+//     holds FOUR CONSECUTIVE CHANNELS of one time row: the epilogue is one 16-byte load / store per tile instead
+//     of sixteen 4-byte ones, and the conv1 -> conv2 hand-off of the fused pair is one ds_write_b64 per tile and
+//     image instead of thirty-two ds_write_b16.
+//   * Pipeline.  The weight ring has three slots filled by LDS-DMA two slices ahead and is synchronised with raw
+//     s_barrier + counted vmcnt (nothing drains the DMA queue).  In the single-conv kernel the one barrier per step
+//     sits BEFORE THE LAST SUB-STEP of the step, so the A fragments of the next slice are requested while the last
+//     MFMAs of the current one issue and no step starts with an LDS round trip (the round-1 kernels began every
+//     step with 16 ds_read_b128 + lgkmcnt(0) in all eight waves at once); its activation window is double-buffered
+//     per 32-channel chunk (128-row tile): chunk c+1 is converted and written while chunk c multiplies.
+//
+// Layouts
+//   activations  [B][T][C] fp32 channels-last in HBM (unchanged);
+//   window (LDS) per 32-channel chunk, per image (hi, lo): 4 planes kq = (c % 32) / 8 of [row][8 halfs] (16 B per
+//                row): a B fragment (lane = time l & 15, k = 8 (l >> 4) + j) is one conflict-free ds_read_b128 for
+//                ANY row offset (16 consecutive 16-byte units per lane group);
+//   weights      packed on the host in A-fragment order [chunk32][tap][m-tile][hi|lo][lane][8 halfs]
+//                (lane = row l & 15, k = 8 (l >> 4) + j): a (chunk, tap) slice of a block's m-tiles is one
+//                contiguous run, copied by global_load_lds_dwordx4 in 1 KiB pieces.
+//   transposed conv: the `phases` = stride polyphase GEMMs are stacked along M (row = phase * Cout + co): one
+//                block computes its rows of all phases from ONE window; D row (ph, co) of input time q is stored
+//                at output row phases * q + ph - ups_p.
+//
+// Reference call sites: modules.py:210-223 (ResBlock1), models.py:255-257, 276-285 (ups, resblock averaging).
+#include "kernels.h"
+
+#include <cstdlib>
+#include <cstring>
+
+namespace vsp {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int G16_HALO = 64;   // max (K-1)*dil
+constexpr int G16_OOR = 0x7ffffff0;   // byte offset outside every buffer descriptor: loads give 0, stores are dropped
+
+size_t packed_g16_halfs(int rows, int Cin, int K) { return (size_t)K * Cin * rows * 2; }
+
+// dense: W[row][ci][tap] fp32 (row = phase * Cout + co for a transposed conv) -> interleaved hi / lo fragment blocks
+void pack_g16_weights(uint16_t* dst, int rows, int Cin, int K, const float* dense) {
+  const int nmt = rows / 16;
+  for (int r = 0; r < rows; ++r)
+    for (int ci = 0; ci < Cin; ++ci)
+      for (int tap = 0; tap < K; ++tap) {
+        const float w = dense[((size_t)r * Cin + ci) * K + tap];
+        const _Float16 h = (_Float16)w;
+        const _Float16 l = (_Float16)((w - (float)h) * 2048.f);
+        const int chunk = ci / 32, kk = ci % 32, mt = r / 16, lane = (r % 16) + 16 * (kk / 8), j = kk % 8;
+        const size_t blk = (((size_t)chunk * K + tap) * nmt + mt) * 2;
+        std::memcpy(dst + (blk * 64 + lane) * 8 + j, &h, 2);
+        std::memcpy(dst + ((blk + 1) * 64 + lane) * 8 + j, &l, 2);
+      }
+}
+
+// one asm statement: the "memory" clobber keeps the compiler from moving LDS traffic across the barrier; LDS-DMA
+// and global loads stay in flight (no vmcnt here)
+#define G16_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n: "at most n vector-memory operations outstanding".  They retire
+// in issue order, so n = the number of operations issued AFTER the one that must have landed.
+__device__ __forceinline__ void g16_vm_wait(int n) {
+#define G16_VMC(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+  switch (n) {
+    G16_VMC(1) G16_VMC(2) G16_VMC(3) G16_VMC(4) G16_VMC(5) G16_VMC(6) G16_VMC(7) G16_VMC(8) G16_VMC(9) G16_VMC(10)
+    G16_VMC(11) G16_VMC(12)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef G16_VMC
+}
+
+// leaky-relu + split of four fp32 values -> hi / lo f16x4
+__device__ __forceinline__ void g16_split4(const f32x4 v, float slope, bool act, f16x4& eh, f16x4& el) {
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    f32x2 x = {v[2 * k], v[2 * k + 1]};
+    if (act) {
+      const f32x2 y = x * slope;
+      asm("v_max_f32 %0, %1, %2" : "=v"(x.x) : "v"(x.x), "v"(y.x));   // leaky-relu = max(x, slope*x), 0 <= slope <= 1
+      asm("v_max_f32 %0, %1, %2" : "=v"(x.y) : "v"(x.y), "v"(y.y));
+    }
+    const f16x2 xh = __builtin_convertvector(x, f16x2);
+    const f32x2 back = __builtin_convertvector(xh, f32x2);
+    const f16x2 xl = __builtin_convertvector((x - back) * 2048.f, f16x2);
+    eh[2 * k] = xh.x; eh[2 * k + 1] = xh.y;
+    el[2 * k] = xl.x; el[2 * k + 1] = xl.y;
+  }
+}
+__device__ __forceinline__ f32x4 g16_as_f32x4(const u32x4 v) {
+  return f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+}
+__device__ __forceinline__ u32x4 g16_as_u32x4(const f32x4 v) {
+  return u32x4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Single convolution (and polyphase transposed convolution).  Block = WM x WN waves; a wave owns MW m-tiles
+// (16 output rows each) x NW n-tiles (16 time columns each).  Contraction runs chunk-major: for each 32-channel
+// chunk, for each tap: one "step" = MW*NW*3 MFMAs per wave, NW sub-steps of MW*3.
+//   NXB = 2: the window is double-buffered per chunk (no exposed chunk transition); NXB = 1: one buffer, two
+//   barriers around the re-staging (small tiles that want two blocks per CU).
+template <int MW, int NW, int WM, int WN, int NXB, int TERMS>
+__global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
+  constexpr int NWV = WM * WN, NTH = 64 * NWV;
+  constexpr int BT = 16 * NW * WN;              // time columns per block
+  constexpr int MTB = MW * WM;                  // m-tiles per block
+  constexpr int WR = BT + G16_HALO;             // window rows allocated
+  constexpr int PL = WR * 16;                   // bytes per plane
+  constexpr int XIMG = 4 * PL;                  // bytes per image
+  constexpr int XBUF = 2 * XIMG;                // hi + lo
+  constexpr int SLOT = MTB * 2048;              // bytes per ring slot = one (chunk, tap) slice of the block's rows
+  constexpr int NS = 3;
+  constexpr int RPS = NTH / 8;                  // rows per staging sweep
+  constexpr int NL = (WR + RPS - 1) / RPS;
+  constexpr int NBLK = 2 * MTB;                 // 1 KiB pieces per slice
+  constexpr int NBW = (NBLK + NWV - 1) / NWV;   // per wave
+  static_assert(PL % 256 == 0, "plane size keeps the fragment reads conflict-free");
+  static_assert(NW % 2 == 0, "B double buffer parity");
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* const Xw = lds;
+  char* const Rg = lds + NXB * XBUF;
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int wm = wave / WN, wn = wave % WN;
+  const int nmt = (a.phases * a.Cout) >> 4, nch = a.Cin >> 5;
+  // XCD-aware block numbering (as in conv_f16s.hip): XCD k gets the k-th contiguous eighth of the
+  // (utterance, time tile, row group) sequence, row group fastest
+  const int gy = gridDim.y, gx = gridDim.x;
+  const int nwg = gx * gy * gridDim.z, orig = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+  const int xcd = orig & 7, qd = nwg >> 3, rem = nwg & 7;
+  const int id = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (orig >> 3);
+  const int cb = id % gy, bx = (id / gy) % gx, b = id / (gy * gx);
+  const int t0 = bx * BT;
+  const int K = a.K, S = nch * K;
+  const int xrows = BT + (K - 1) * a.dil;        // window rows actually needed
+
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x) + (size_t)b * a.x_bs, 0, a.T_in * a.x_ts * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+      a.out + (size_t)b * a.o_bs, 0, a.T_store * a.o_ts * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr_ = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.res ? a.res : a.out) + (size_t)b * (a.res ? a.r_bs : a.o_bs), 0,
+      a.T_store * (a.res ? a.r_ts : a.o_ts) * 4, 0x00020000);
+
+  // ---- window staging: 16 consecutive lanes write 128 contiguous bytes of one plane (conflict-free)
+  const int g16 = tid >> 4, kq_s = g16 & 3, row_s = (g16 >> 2) * 8 + ((tid >> 1) & 7), half_s = tid & 1;
+  const int st_voff = (row_s * a.x_ts + (2 * kq_s + half_s) * 4) * 4;
+  const int st_loff = kq_s * PL + row_s * 16 + half_s * 8;
+  u32x4 sv[NL];
+  const float slope = a.in_slope;
+  const bool act = a.in_act != 0;
+  auto x_issue = [&](int chunk) {
+    const int base = ((t0 - a.pad) * a.x_ts + chunk * 32) * 4;            // uniform, may be negative
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+      const bool in = (u + 1) * RPS <= BT || row_s + u * RPS < xrows;
+      sv[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, in ? st_voff + (base + u * RPS * a.x_ts * 4) : G16_OOR, 0, 0);
+    }
+  };
+  auto x_write = [&](int buf) {
+    char* dst0 = Xw + buf * XBUF + st_loff;
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+      f16x4 eh, el;
+      g16_split4(g16_as_f32x4(sv[u]), slope, act, eh, el);
+      if ((u + 1) * RPS <= BT || row_s + u * RPS < xrows) {
+        *reinterpret_cast<f16x4*>(dst0 + u * RPS * 16) = eh;
+        if constexpr (TERMS == 3) *reinterpret_cast<f16x4*>(dst0 + u * RPS * 16 + XIMG) = el;
+      }
+    }
+  };
+  // ---- weight slices by LDS-DMA: slice (chunk, tap) = NBLK pieces of 1 KiB, contiguous in the packed image.
+  //      The cursor (dc, dt) walks the slices in step order.
+  const uint4* Wg = reinterpret_cast<const uint4*>(a.wh);
+  int dc = 0, dt = 0;
+  auto dma_next = [&](int slot) {
+    const size_t src = (((size_t)dc * K + dt) * nmt + (size_t)cb * MTB) * 128;   // uint4 units (2 KiB per m-tile)
+#pragma unroll
+    for (int u = 0; u < NBW; ++u) {
+      const int blk = u * NWV + wave;
+      if (NBLK % NWV == 0 || blk < NBLK) {
+        const uint4* gp = Wg + src + (size_t)blk * 64 + lane;
+        char* lp = Rg + slot * SLOT + blk * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                         (__attribute__((address_space(3))) void*)lp, 16, 0, 0);
+      }
+    }
+    if (++dt == K) { dt = 0; ++dc; }
+  };
+  // pieces of a slice issued by THIS wave (the counted waits below need the exact number)
+  int my_pieces = 0;
+#pragma unroll
+  for (int u = 0; u < NBW; ++u) my_pieces += (NBLK % NWV == 0 || u * NWV + wave < NBLK) ? 1 : 0;
+
+  // ---- fragments
+  const int xb_lane = (lane >> 4) * PL + (wn * NW * 16 + (lane & 15)) * 16;
+  const int wa_lane = lane * 16 + wm * MW * 2048;
+  f16x8 Ah[MW], Al[MW], Bh[2], Bl[2];
+  auto loadA = [&](int i, int slot) {
+    const char* p = Rg + slot * SLOT + wa_lane + i * 2048;
+    Ah[i] = *reinterpret_cast<const f16x8*>(p);
+    if constexpr (TERMS == 3) Al[i] = *reinterpret_cast<const f16x8*>(p + 1024);
+  };
+  auto loadB = [&](int which, int buf, int tap, int j) {
+    const char* p = Xw + buf * XBUF + xb_lane + (tap * a.dil + j * 16) * 16;
+    Bh[which] = *reinterpret_cast<const f16x8*>(p);
+    if constexpr (TERMS == 3) Bl[which] = *reinterpret_cast<const f16x8*>(p + XIMG);
+  };
+
+  // accumulators start at the bias: a lane holds rows 4 (l >> 4) .. + 3 of its m-tiles
+  f32x4 hh[MW][NW], cr[MW][NW];
+#pragma unroll
+  for (int i = 0; i < MW; ++i) {
+    const int row = ((cb * MTB + wm * MW + i) << 4) + 4 * (lane >> 4);
+    const int co = row % a.Cout;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + co);
+#pragma unroll
+    for (int j = 0; j < NW; ++j) { hh[i][j] = bv; cr[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  }
+
+  // ---- prologue: window chunk 0, slices 0 and 1 (then 2 behind the first barrier)
+  x_issue(0);
+  dma_next(0);
+  if (S > 1) dma_next(1);
+  x_write(0);                       // (the compiler waits for the window loads here)
+  int xl_a = 0, xl_b = 0;           // window loads issued behind slice s+1 / s+2 (still counted by vmcnt)
+  if (nch > 1) { x_issue(1); xl_a = 1; }
+  g16_vm_wait(xl_a * NL);           // slices 0 and 1 have landed
+  G16_BARRIER();
+  if (S > 2) dma_next(2);
+#pragma unroll
+  for (int i = 0; i < MW; ++i) loadA(i, 0);
+  loadB(0, 0, 0, 0);
+
+  int chunk = 0, tap = 0, slot = 0;   // of the current step
+  for (int s = 0; s < S; ++s) {
+    const bool last_tap = tap == K - 1;
+    const int chunk_n = last_tap ? chunk + 1 : chunk, tap_n = last_tap ? 0 : tap + 1;   // of step s + 1
+    const bool more = s + 1 < S;
+    const bool wr_step = last_tap && chunk + 1 < nch;      // window chunk + 1 is written in this step
+    const int buf = NXB == 2 ? (chunk & 1) : 0, buf_n = NXB == 2 ? (chunk_n & 1) : 0;
+    const int slot_n = slot == NS - 1 ? 0 : slot + 1;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      if (j == NW - 1 && more) {
+        // ---- the step's barrier point: everything of slice s is in registers
+        if (wr_step) {
+          if constexpr (NXB == 1) G16_BARRIER();            // every wave is done reading the window
+          x_write(buf_n);
+        }
+        // slice s + 1 has landed.  Issued after it: slice s + 2 and the window loads of the last two barrier points
+        g16_vm_wait((s + 2 < S ? my_pieces : 0) + (xl_a + xl_b) * NL);
+        G16_BARRIER();
+        if (s + 3 < S) dma_next(slot);                      // into the slot slice s just left
+        xl_a = xl_b;
+        xl_b = 0;
+        if (wr_step && chunk + 2 < nch) { x_issue(chunk + 2); xl_b = 1; }
+      }
+      // B fragment of the next sub-step (of the next step's first sub-step at the end)
+      if (j + 1 < NW) loadB((j + 1) & 1, buf, tap, j + 1);
+      else if (more) loadB((j + 1) & 1, buf_n, tap_n, 0);
+#pragma unroll
+      for (int i = 0; i < MW; ++i) {
+        hh[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[i], Bh[j & 1], hh[i][j], 0, 0, 0);
+        if constexpr (TERMS == 3) {
+          cr[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al[i], Bh[j & 1], cr[i][j], 0, 0, 0);
+          cr[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[i], Bl[j & 1], cr[i][j], 0, 0, 0);
+        }
+        if (j == NW - 1 && more) loadA(i, slot_n);          // in place: the A fragments of slice s + 1
+      }
+    }
+    chunk = chunk_n;
+    tap = tap_n;
+    slot = slot_n;
+  }
+
+  // ---- epilogue: lane = 4 consecutive rows (channels) of one time column: 16-byte accesses
+#pragma unroll
+  for (int i = 0; i < MW; ++i) {
+    const int row = ((cb * MTB + wm * MW + i) << 4) + 4 * (lane >> 4);
+    const int ph = row / a.Cout, co = row - ph * a.Cout;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int t = t0 + (wn * NW + j) * 16 + (lane & 15);
+      const int n = a.phases * t + ph - a.ups_p;            // output row (< 0 or >= T_store: dropped by the descriptor)
+      const bool in_t = t < a.Nq;
+      const int oo = in_t ? n * a.o_ts * 4 + co * 4 : G16_OOR;
+      f32x4 v;
+      if constexpr (TERMS == 3) v = hh[i][j] + cr[i][j] * (1.f / 2048.f);
+      else v = hh[i][j];
+      if (a.res) v += g16_as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(rr_, in_t ? n * a.r_ts * 4 + co * 4 : G16_OOR, 0, 0));
+      if (a.acc_prev) v += g16_as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(ro, oo, 0, 0));
+      if (a.div != 1.f) v /= a.div;
+      __builtin_amdgcn_raw_buffer_store_b128(g16_as_u32x4(v), ro, oo, 0, 0);
+    }
+  }
+}
+
+template <int MW, int NW, int WM, int WN, int NXB, int TERMS>
+static hipError_t launch_g16_tile(const ClConvArgs& a, int B, hipStream_t s) {
+  constexpr int BT = 16 * NW * WN, MTB = MW * WM;
+  constexpr size_t lds = (size_t)NXB * 2 * 4 * (BT + G16_HALO) * 16 + (size_t)3 * MTB * 2048;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  static bool attr_set = false;
+  auto kern = g16_conv<MW, NW, WM, WN, NXB, TERMS>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int nmt = a.phases * a.Cout / 16;
+  if (nmt % MTB || a.Cin % 32) return hipErrorInvalidValue;
+  dim3 grid((a.Nq + BT - 1) / BT, nmt / MTB, B);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_g16_conv(const ClConvArgs& a, int B, hipStream_t s) {
+  if ((a.K - 1) * a.dil > G16_HALO || a.K < 1 || a.Nq <= 0 || B <= 0 || a.Cout % 16 || a.Cin % 32 || a.phases < 1 ||
+      (a.x_ts & 3) || (a.x_bs & 3) || (reinterpret_cast<uintptr_t>(a.x) & 15) || (a.o_ts & 3) || (a.o_bs & 3) ||
+      (reinterpret_cast<uintptr_t>(a.out) & 15))
+    return hipErrorInvalidValue;
+  const int rows = a.phases * a.Cout;
+  // <MW, NW, WM, WN, NXB, TERMS>
+  if (a.terms == 1) {
+    if (rows % 128 == 0) return launch_g16_tile<4, 4, 2, 4, 2, 1>(a, B, s);
+    if (rows % 64 == 0) return launch_g16_tile<4, 2, 1, 8, 1, 1>(a, B, s);
+    if (rows % 32 == 0) return launch_g16_tile<2, 2, 1, 8, 1, 1>(a, B, s);
+    return hipErrorInvalidValue;
+  }
+  if (rows % 128 == 0) return launch_g16_tile<4, 4, 2, 4, 2, 3>(a, B, s);   // 128 rows x 256 columns, one block per CU
+  if (rows % 64 == 0) return launch_g16_tile<4, 2, 1, 8, 1, 3>(a, B, s);    //  64 rows x 256 columns, two blocks per CU
+  if (rows % 32 == 0) return launch_g16_tile<2, 2, 1, 8, 1, 3>(a, B, s);    //  32 rows x 256 columns
+  return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Fused ResBlock1 conv PAIR of the 32- and 64-channel stages (reference modules.py:210-223):
+//     y = x + conv2(lrelu(conv1(lrelu(x), dilation d) + b1), dilation 1) + b2   [+ previous sum] [/ div]
+// One block = 8 waves x 32 time columns: conv1 on 256 columns from the staged x window, its tile (bias added,
+// columns outside the utterance zeroed = conv2's padding) activated, split and written over the dead window as
+// conv2's B image, conv2 on 256 - (K-1) columns, residual + store.  The intermediate never leaves the CU.
+// The arithmetic per output (chunk-major, tap-minor, HH / CROSS / CROSS per step, bias in the accumulator) is that of
+// g16_conv, so the result is bit-identical to the two-launch path.
+//   NCH = C / 32 (1 or 2); G = taps per ring slot.
+template <int NCH, int G, int TERMS>
+__global__ void __launch_bounds__(512, 4) g16_pair(ClPairArgs a) {
+  constexpr int MW = 2 * NCH, NW = 2, NWV = 8, C = 32 * NCH;
+  constexpr int BT = 256, WR = BT + G16_HALO, PL = WR * 16, XIMG = 4 * PL, XBUF = 2 * XIMG;
+  constexpr int TAPB = MW * 2048;               // bytes of one tap in a ring slot
+  constexpr int SLOT = G * TAPB;
+  constexpr int NS = 3, RPS = 64, NL = (WR + RPS - 1) / RPS;
+  constexpr int NPT = 2 * MW;                   // 1 KiB pieces per tap
+  constexpr int NBWMAX = (G * NPT + NWV - 1) / NWV;
+  constexpr bool EARLY_RES = NCH == 1 && TERMS == 3;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* const Xw = lds;                         // x window chunk, later the t image chunk
+  char* const Rg = lds + XBUF;
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, q4 = lane >> 4, l15 = lane & 15;
+
+  // XCD-aware tile numbering: XCD k gets the k-th contiguous eighth of the (utterance, tile) sequence
+  const int nwg = gridDim.x, orig = blockIdx.x;
+  const int xcd = orig & 7, qd = nwg >> 3, rem = nwg & 7;
+  const int id = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (orig >> 3);
+  const int b = id / a.tiles, tile = id - b * a.tiles;
+
+  const int K = a.K, p2 = (K - 1) >> 1, p1 = a.dil * p2;
+  const int R2 = BT - (K - 1);                  // output columns per block
+  const int t0 = tile * R2;                     // first output column
+  const int ns = (K + G - 1) / G;               // slices per chunk
+  const int S1 = NCH * ns, S = 2 * S1;
+  const int xrows = BT + (K - 1) * a.dil;
+
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x) + (size_t)b * a.x_bs, 0, a.T * C * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)b * a.o_bs, 0, a.T * C * 4,
+                                                                      0x00020000);
+
+  // ---- x window staging (as in g16_conv): row 0 of the window is time t0 - p2 - p1
+  const int g16 = tid >> 4, kq_s = g16 & 3, row_s = (g16 >> 2) * 8 + ((tid >> 1) & 7), half_s = tid & 1;
+  const int st_voff = (row_s * C + (2 * kq_s + half_s) * 4) * 4;
+  const int st_loff = kq_s * PL + row_s * 16 + half_s * 8;
+  u32x4 sv[NL];
+  const float slope = a.slope;
+  auto x_issue = [&](int chunk) {
+    const int base = ((t0 - p2 - p1) * C + chunk * 32) * 4;
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+      const bool in = (u + 1) * RPS <= BT || row_s + u * RPS < xrows;
+      sv[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, in ? st_voff + (base + u * RPS * C * 4) : G16_OOR, 0, 0);
+    }
+  };
+  auto x_write = [&]() {
+    char* dst0 = Xw + st_loff;
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+      f16x4 eh, el;
+      g16_split4(g16_as_f32x4(sv[u]), slope, true, eh, el);
+      if ((u + 1) * RPS <= BT || row_s + u * RPS < xrows) {
+        *reinterpret_cast<f16x4*>(dst0 + u * RPS * 16) = eh;
+        if constexpr (TERMS == 3) *reinterpret_cast<f16x4*>(dst0 + u * RPS * 16 + XIMG) = el;
+      }
+    }
+  };
+
+  // ---- weight slices: global slice index s in [0, S): conv = s / S1, then chunk-major, G taps per slice.
+  //      Cursor of the next slice to request: (dv, dc, dsl); returns the pieces THIS wave issued.
+  int dv = 0, dc = 0, dsl = 0;
+  auto dma_next = [&](int slot) -> int {
+    const uint4* Wg = reinterpret_cast<const uint4*>(dv ? a.w2h : a.w1h);
+    const int tap0 = dsl * G;
+    const int pieces = ((K - tap0) < G ? (K - tap0) : G) * NPT;
+    const size_t src = ((size_t)dc * K + tap0) * MW * 128;        // uint4 units
+    int mine = 0;
+#pragma unroll
+    for (int u = 0; u < NBWMAX; ++u) {
+      const int p = u * NWV + wave;
+      if (p < pieces) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wg + src + (size_t)p * 64 + lane),
+                                         (__attribute__((address_space(3))) void*)(Rg + slot * SLOT + p * 1024), 16, 0, 0);
+        ++mine;
+      }
+    }
+    if (++dsl == ns) { dsl = 0; if (++dc == NCH) { dc = 0; ++dv; } }
+    return mine;
+  };
+
+  // ---- fragments
+  const int xb_lane = q4 * PL + (wave * 32 + l15) * 16;
+  const int wa_lane = lane * 16;
+  f32x4 hh[MW][NW], cr[MW][NW];
+  // MFMAs of one slice: taps [tap0, tap0 + nt) of one chunk; rowstep = dilation of the conv
+  auto slice = [&](int slot, int tap0, int nt, int rowstep) {
+    for (int g = 0; g < nt; ++g) {
+      f16x8 Bh[NW], Bl[NW];
+      const char* pb = Xw + xb_lane + (tap0 + g) * rowstep * 16;
+#pragma unroll
+      for (int j = 0; j < NW; ++j) {
+        Bh[j] = *reinterpret_cast<const f16x8*>(pb + j * 256);
+        if constexpr (TERMS == 3) Bl[j] = *reinterpret_cast<const f16x8*>(pb + j * 256 + XIMG);
+      }
+      const char* pa = Rg + slot * SLOT + g * TAPB + wa_lane;
+#pragma unroll
+      for (int i = 0; i < MW; ++i) {
+        f16x8 Ah, Al;
+        Ah = *reinterpret_cast<const f16x8*>(pa + i * 2048);
+        if constexpr (TERMS == 3) Al = *reinterpret_cast<const f16x8*>(pa + i * 2048 + 1024);
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+          hh[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bh[j], hh[i][j], 0, 0, 0);
+          if constexpr (TERMS == 3) {
+            cr[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bh[j], cr[i][j], 0, 0, 0);
+            cr[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bl[j], cr[i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+  };
+  auto init_acc = [&](const float* bias) {
+#pragma unroll
+    for (int i = 0; i < MW; ++i) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 16 * i + 4 * q4);
+#pragma unroll
+      for (int j = 0; j < NW; ++j) { hh[i][j] = bv; cr[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
+  };
+
+  // ================= prologue =================
+  // EARLY_RES: the residual values are requested together with the window -- same lines at the same time, so the
+  // second request hits L2 (by epilogue time they would have left it: a second HBM pass)
+  [[maybe_unused]] u32x4 res_early[MW][NW];
+  if constexpr (EARLY_RES) {
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+      for (int j = 0; j < NW; ++j) {
+        const int r = wave * 32 + 16 * j + l15;
+        res_early[i][j] = __builtin_amdgcn_raw_buffer_load_b128(rx, r < R2 ? (t0 + r) * C * 4 + (16 * i + 4 * q4) * 4 : G16_OOR, 0, 0);
+      }
+  }
+  init_acc(a.b1);
+  x_issue(0);
+  int pc_a = dma_next(0);            // pieces of slice s + 1 / s + 2 issued by this wave (for the counted waits)
+  int pc_b = dma_next(1);
+  x_write();
+  int xl_a = 0, xl_b = 0;            // window loads issued behind slice s + 1 / s + 2
+  int slot = 0;
+  // at the top of step s: slices s and s + 1 are in flight or landed; pc_a / pc_b = my pieces of s + 1 / s + 2
+  // (rotated below).  The invariant on entry: pc_a = pieces(slice 0)... kept as (cur, next) pair:
+  int pc_cur = pc_a, pc_nxt = pc_b;
+  (void)pc_cur;
+
+  // ================= conv1 =================
+  int chunk = 0, sl = 0;
+  for (int s = 0; s < S1; ++s) {
+    // slice s has landed: issued after it are slice s + 1 and the window loads of the last two steps
+    g16_vm_wait(pc_nxt + (xl_a + xl_b) * NL);
+    G16_BARRIER();                                   // slice s (and a freshly written window) visible to all
+    pc_cur = pc_nxt;
+    pc_nxt = s + 2 < S ? dma_next(slot == 0 ? 2 : slot - 1) : 0;     // slot of slice s - 1
+    xl_a = xl_b;
+    xl_b = 0;
+    const bool last_sl = sl == ns - 1;
+    if constexpr (NCH > 1) {
+      // the next chunk's window is requested two slices before its staging (or at the chunk's start)
+      if (chunk + 1 < NCH && sl == (ns > 2 ? ns - 3 : 0)) { x_issue(chunk + 1); xl_b = 1; }
+    }
+    const int tap0 = sl * G;
+    slice(slot, tap0, (K - tap0) < G ? (K - tap0) : G, a.dil);
+    if constexpr (NCH > 1) {
+      if (last_sl && chunk + 1 < NCH) {
+        G16_BARRIER();                               // every wave is done reading this chunk's window
+        x_write();
+      }
+    }
+    slot = slot == NS - 1 ? 0 : slot + 1;
+    if (last_sl) { sl = 0; ++chunk; } else ++sl;
+  }
+
+  // conv1 tile -> activated fp32 values (bias is in hh); columns outside the utterance are conv2's zero padding
+  f32x4 tv[MW][NW];
+#pragma unroll
+  for (int j = 0; j < NW; ++j) {
+    const int tt = t0 - p2 + wave * 32 + 16 * j + l15;
+    const bool valid = tt >= 0 && tt < a.T;
+#pragma unroll
+    for (int i = 0; i < MW; ++i) {
+      f32x4 v;
+      if constexpr (TERMS == 3) v = hh[i][j] + cr[i][j] * (1.f / 2048.f);
+      else v = hh[i][j];
+      tv[i][j] = valid ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+
+  // ================= conv2 =================
+  init_acc(a.b2);
+#pragma unroll
+  for (int c2 = 0; c2 < NCH; ++c2) {
+    // t image chunk c2 = conv1 output channels [32 c2, 32 c2 + 32) = m-tiles 2 c2, 2 c2 + 1: a lane's four channels
+    // 16 i + 4 q4 .. + 3 sit in plane 2 (i & 1) + (q4 >> 1) at byte 8 (q4 & 1) of the row's 16
+    G16_BARRIER();                                   // nobody still reads the region (window / previous t chunk)
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < NW; ++j) {
+        f16x4 eh, el;
+        g16_split4(tv[2 * c2 + ii][j], slope, true, eh, el);
+        char* dst = Xw + (2 * ii + (q4 >> 1)) * PL + (wave * 32 + 16 * j + l15) * 16 + 8 * (q4 & 1);
+        *reinterpret_cast<f16x4*>(dst) = eh;
+        if constexpr (TERMS == 3) *reinterpret_cast<f16x4*>(dst + XIMG) = el;
+      }
+    for (int sl2 = 0; sl2 < ns; ++sl2) {
+      const int s = S1 + c2 * ns + sl2;
+      g16_vm_wait(pc_nxt + (xl_a + xl_b) * NL);
+      G16_BARRIER();
+      pc_cur = pc_nxt;
+      pc_nxt = s + 2 < S ? dma_next(slot == 0 ? 2 : slot - 1) : 0;
+      xl_a = xl_b;
+      xl_b = 0;
+      const int tap0 = sl2 * G;
+      slice(slot, tap0, (K - tap0) < G ? (K - tap0) : G, 1);
+      slot = slot == NS - 1 ? 0 : slot + 1;
+    }
+  }
+
+  // ---- epilogue: y = conv2 + x (+ previous resblock sum) (/ div); columns >= R2 belong to the next tile
+#pragma unroll
+  for (int i = 0; i < MW; ++i)
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int r = wave * 32 + 16 * j + l15;
+      const int off = r < R2 ? (t0 + r) * C * 4 + (16 * i + 4 * q4) * 4 : G16_OOR;
+      f32x4 v;
+      if constexpr (TERMS == 3) v = hh[i][j] + cr[i][j] * (1.f / 2048.f);
+      else v = hh[i][j];
+      if constexpr (EARLY_RES) v += g16_as_f32x4(res_early[i][j]);
+      else v += g16_as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+      if (a.acc_prev) v += g16_as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(ro, off, 0, 0));
+      if (a.div != 1.f) v /= a.div;
+      __builtin_amdgcn_raw_buffer_store_b128(g16_as_u32x4(v), ro, off, 0, 0);
+    }
+}
+
+template <int NCH, int G, int TERMS>
+static hipError_t launch_g16_pair_tile(ClPairArgs a, int B, hipStream_t s) {
+  constexpr size_t lds = (size_t)2 * 4 * (256 + G16_HALO) * 16 + (size_t)3 * G * 2 * NCH * 2048;
+  static_assert(lds <= 80 * 1024, "two blocks per CU");
+  static bool attr_set = false;
+  auto kern = g16_pair<NCH, G, TERMS>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int R2 = 256 - (a.K - 1);
+  a.tiles = (a.T + R2 - 1) / R2;
+  const long n = (long)a.tiles * B;
+  if (n <= 0 || n > 0x7fffffffL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(512), lds, s, a);
+  return hipGetLastError();
+}
+
+bool g16_pair_supported(int C, int K, int dil) {
+  return (C == 32 || C == 64) && K >= 1 && (K & 1) && (K - 1) * dil <= G16_HALO && K - 1 < 128;
+}
+
+hipError_t launch_g16_pair(const ClPairArgs& a, int B, hipStream_t s) {
+  if (!g16_pair_supported(a.C, a.K, a.dil) || a.T <= 0 || B <= 0 || (a.x_bs & 3) || (a.o_bs & 3) ||
+      (reinterpret_cast<uintptr_t>(a.x) & 15) || (reinterpret_cast<uintptr_t>(a.out) & 15) || a.x == a.out)
+    return hipErrorInvalidValue;
+  if (a.terms == 1) return a.C == 32 ? launch_g16_pair_tile<1, 2, 1>(a, B, s) : launch_g16_pair_tile<2, 1, 1>(a, B, s);
+  return a.C == 32 ? launch_g16_pair_tile<1, 2, 3>(a, B, s) : launch_g16_pair_tile<2, 1, 3>(a, B, s);
+}
+
+}  // namespace vsp

@@ -80,6 +80,13 @@ bool cl_pair_supported(int C, int K, int dil);
 hipError_t launch_cl_pair(const ClPairArgs& a, int B, hipStream_t s);
 size_t packed_cl_halfs(int Cout, int Cin, int K, int phases);
 void pack_cl_weights(uint16_t* hi, uint16_t* lo, int Cout, int Cin, int K, int phases, const float* dense);
+// second generation of the two kernels above on v_mfma_f32_16x16x32_f16 (gen16.hip): same argument structs, the
+// weights in `wh` / `w1h` / `w2h` are the interleaved hi|lo A-fragment image of pack_g16_weights (wl unused)
+hipError_t launch_g16_conv(const ClConvArgs& a, int B, hipStream_t s);
+bool g16_pair_supported(int C, int K, int dil);
+hipError_t launch_g16_pair(const ClPairArgs& a, int B, hipStream_t s);
+size_t packed_g16_halfs(int rows, int Cin, int K);
+void pack_g16_weights(uint16_t* dst, int rows, int Cin, int K, const float* dense /* [rows][Cin][K] */);
 hipError_t launch_transpose_ct(const float* x, long x_bs, long x_cs, float* y, long y_bs, int y_ts, int B, int C,
                                int T, hipStream_t s);
 hipError_t launch_conv_post_cl(const float* x, long x_bs, int x_ts, const float* w, int C, int K, float slope,

@@ -31,7 +31,8 @@ struct Conv {
 // One channels-last split-f16 conv (conv_f16s.hip); wh / wl offsets in floats (2 halfs per float).
 struct ClConv {
   int Cout = 0, Cin = 0, K = 1, dil = 1, pad = 0, phases = 1, ups_p = 0;
-  size_t wh = 0, wl = 0;
+  size_t wh = 0, wl = 0;   // 32x32x16 fragment images (conv_f16s.hip / respair_f16s.hip)
+  size_t wg = 0;           // 16x16x32 interleaved hi|lo A-fragment image (gen16.hip)
   long b = -1;
 };
 
@@ -108,15 +109,18 @@ struct vsp_ctx {
                      // 2: same kernels with plain f16 operands (VSP_GENERATOR=f16, opt-in reduced precision)
   bool frame_f16s = true;  // frame/phoneme-rate convs on the split-f16 matrix path (VSP_FRAME=f32: f32 MFMA)
   int att_ksplit = -1;     // attention key-split blocks: -1 automatic (under-filled grids), 0 never, 1 always (VSP_ATT_KSPLIT)
+  bool gen16 = true;       // generator convs on the 16x16x32 kernels of gen16.hip (VSP_GEN16=0: the round-1 32x32x16 kernels)
   bool fuse_pairs = true;  // ResBlock conv pairs of the 32/64-channel stages as one launch (VSP_FUSE_PAIRS=0: two launches)
   double chunk_mb = 0.0;   // generator batch chunk in MiB per activation tensor (VSP_CHUNK_MB; 0 = whole batch: measured faster)
-  // profiling of the dominant kernel
+  // profiling: HIP event pairs around the launches of a class (VSP_PROF_* in vispeech_hip.h)
   bool prof_on = false;
   std::vector<hipEvent_t> ev_pool;
+  std::vector<int> ev_cls;           // class of event pair i (events 2i, 2i+1)
   size_t ev_used = 0;
-  int64_t prof_launches = 0;
-  double prof_flops = 0.0;
-  double prof_bytes = 0.0;
+  int64_t prof_launches[VSP_PROF_CLASSES] = {};
+  double prof_flops[VSP_PROF_CLASSES] = {};
+  double prof_bytes[VSP_PROF_CLASSES] = {};       // input once + output once per convolution
+  double prof_bytes_ext[VSP_PROF_CLASSES] = {};   // the same plus residual / accumulate operand reads
 
   int fail(int code, const char* fmt, ...) {
     char buf[512];
