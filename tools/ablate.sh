@@ -5,5 +5,5 @@ set -e
 cd "$(dirname "$0")/../vispeech_amd/csrc"
 for D in "$@"; do
   mkdir -p ../../build/diag$D
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DVSP_DIAG=$D -shared conv_mfma.hip conv_f16s.hip respair_f16s.hip attention.hip misc.hip api.hip -x hip weights.cpp -o ../../build/diag$D/libvispeech_hip.so 2>&1 | grep -E "error" || true
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DVSP_DIAG=$D -DG16_DIAG=$D -shared conv_mfma.hip conv_f16s.hip respair_f16s.hip gen16.hip attention.hip misc.hip api.hip -x hip weights.cpp -o ../../build/diag$D/libvispeech_hip.so 2>&1 | grep -E "error" || true
 done

@@ -33,6 +33,8 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
+#include <utility>
 
 namespace vsp {
 
@@ -42,6 +44,13 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// G16_DIAG: timing-only ablation builds (tools/ablate.sh; results WRONG by construction): bit 0 no MFMA, bit 1 no
+// weight DMA, bit 2 no barriers, bit 3 no epilogue memory traffic, bit 4 no window loads, bit 5 every weight slice
+// copied from the SAME source bytes (slice 0: L2-hot), bit 6 no vmcnt waits.  0 in the product build.
+#ifndef G16_DIAG
+#define G16_DIAG 0
+#endif
 
 constexpr int G16_HALO = 64;   // max (K-1)*dil
 constexpr int G16_OOR = 0x7ffffff0;   // byte offset outside every buffer descriptor: loads give 0, stores are dropped
@@ -66,18 +75,54 @@ void pack_g16_weights(uint16_t* dst, int rows, int Cin, int K, const float* dens
 
 // one asm statement: the "memory" clobber keeps the compiler from moving LDS traffic across the barrier; LDS-DMA
 // and global loads stay in flight (no vmcnt here)
+#if G16_DIAG & 4
+#define G16_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
 #define G16_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+// f32x4 MFMA wrapper (ablation bit 0 keeps the operands alive without the matrix instruction)
+#if G16_DIAG & 1
+#define G16_MFMA(a, b, c) ([&]() { asm volatile("" ::"v"(a), "v"(b)); return c; }())
+#else
+#define G16_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#endif
 
-// s_waitcnt vmcnt(n) for a wave-uniform run-time n: "at most n vector-memory operations outstanding".  They retire
-// in issue order, so n = the number of operations issued AFTER the one that must have landed.
-__device__ __forceinline__ void g16_vm_wait(int n) {
-#define G16_VMC(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-  switch (n) {
-    G16_VMC(1) G16_VMC(2) G16_VMC(3) G16_VMC(4) G16_VMC(5) G16_VMC(6) G16_VMC(7) G16_VMC(8) G16_VMC(9) G16_VMC(10)
-    G16_VMC(11) G16_VMC(12)
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-  }
-#undef G16_VMC
+// s_waitcnt vmcnt(N): "at most N vector-memory operations outstanding".  They retire in issue order, so N = the
+// number of operations issued AFTER the one that must have landed.  The count is an immediate: the callers pick
+// among the few values that occur (pieces of one slice, plus 0 / 1 / 2 window-load groups of NL loads).
+template <int N>
+__device__ __forceinline__ void g16_vmcnt() {
+  if constexpr ((G16_DIAG & 64) == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+template <int P, int NL>
+__device__ __forceinline__ void g16_vm_wait(bool slice_behind, int groups) {
+  if (groups == 0) { if (slice_behind) g16_vmcnt<P>(); else g16_vmcnt<0>(); }
+  else if (groups == 1) { if (slice_behind) g16_vmcnt<P + NL>(); else g16_vmcnt<NL>(); }
+  else { if (slice_behind) g16_vmcnt<P + 2 * NL>(); else g16_vmcnt<2 * NL>(); }
+}
+
+template <int N>
+__device__ __forceinline__ void g16_lgkmcnt() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+// ds_read_b128 the compiler's wait-count pass does not see: the main loop places its own counted lgkmcnt waits
+// (hipcc waits lgkmcnt(0) at the first use of a fragment requested in the previous loop iteration, which stalls
+// every step on the reads just issued).  LDS operations return in order, so "at most N outstanding" = everything
+// but the N youngest has arrived.  Every wait is followed by a sched_barrier: hipcc would otherwise hoist a
+// register-only MFMA across the asm wait.
+template <int OFF>
+__device__ __forceinline__ f16x8 g16_lds_read(unsigned addr) {
+  f16x8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <class F, int... I>
+__device__ __forceinline__ void g16_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void g16_for(F&& f) {
+  g16_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
 // leaky-relu + split of four fp32 values -> hi / lo f16x4
@@ -108,9 +153,9 @@ __device__ __forceinline__ u32x4 g16_as_u32x4(const f32x4 v) {
 // Single convolution (and polyphase transposed convolution).  Block = WM x WN waves; a wave owns MW m-tiles
 // (16 output rows each) x NW n-tiles (16 time columns each).  Contraction runs chunk-major: for each 32-channel
 // chunk, for each tap: one "step" = MW*NW*3 MFMAs per wave, NW sub-steps of MW*3.
-//   NXB = 2: the window is double-buffered per chunk (no exposed chunk transition); NXB = 1: one buffer, two
-//   barriers around the re-staging (small tiles that want two blocks per CU).
-template <int MW, int NW, int WM, int WN, int NXB, int TERMS>
+// The window is double-buffered per chunk: chunk c + 1 is converted and written during the MEM phase of chunk c's
+// last step (no exposed chunk transition).
+template <int MW, int NW, int WM, int WN, int TERMS>
 __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
   constexpr int NWV = WM * WN, NTH = 64 * NWV;
   constexpr int BT = 16 * NW * WN;              // time columns per block
@@ -120,7 +165,7 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
   constexpr int XIMG = 4 * PL;                  // bytes per image
   constexpr int XBUF = 2 * XIMG;                // hi + lo
   constexpr int SLOT = MTB * 2048;              // bytes per ring slot = one (chunk, tap) slice of the block's rows
-  constexpr int NS = 3;
+  constexpr int NS = 4;
   constexpr int RPS = NTH / 8;                  // rows per staging sweep
   constexpr int NL = (WR + RPS - 1) / RPS;
   constexpr int NBLK = 2 * MTB;                 // 1 KiB pieces per slice
@@ -129,7 +174,7 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
   static_assert(NW % 2 == 0, "B double buffer parity");
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* const Xw = lds;
-  char* const Rg = lds + NXB * XBUF;
+  char* const Rg = lds + 2 * XBUF;
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -160,14 +205,15 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
   const int st_voff = (row_s * a.x_ts + (2 * kq_s + half_s) * 4) * 4;
   const int st_loff = kq_s * PL + row_s * 16 + half_s * 8;
   u32x4 sv[NL];
-  const float slope = a.in_slope;
-  const bool act = a.in_act != 0;
+  const float slope = a.in_act ? a.in_slope : 1.f;   // leaky-relu as max(x, slope * x): slope 1 = identity
+  constexpr bool act = true;
   auto x_issue = [&](int chunk) {
     const int base = ((t0 - a.pad) * a.x_ts + chunk * 32) * 4;            // uniform, may be negative
 #pragma unroll
     for (int u = 0; u < NL; ++u) {
       const bool in = (u + 1) * RPS <= BT || row_s + u * RPS < xrows;
-      sv[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, in ? st_voff + (base + u * RPS * a.x_ts * 4) : G16_OOR, 0, 0);
+      sv[u] = (G16_DIAG & 16) ? u32x4{1u, 2u, 3u, 4u}
+                              : __builtin_amdgcn_raw_buffer_load_b128(rx, in ? st_voff + (base + u * RPS * a.x_ts * 4) : G16_OOR, 0, 0);
     }
   };
   auto x_write = [&](int buf) {
@@ -176,10 +222,9 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
     for (int u = 0; u < NL; ++u) {
       f16x4 eh, el;
       g16_split4(g16_as_f32x4(sv[u]), slope, act, eh, el);
-      if ((u + 1) * RPS <= BT || row_s + u * RPS < xrows) {
-        *reinterpret_cast<f16x4*>(dst0 + u * RPS * 16) = eh;
-        if constexpr (TERMS == 3) *reinterpret_cast<f16x4*>(dst0 + u * RPS * 16 + XIMG) = el;
-      }
+      // (rows >= xrows were loaded as zeros and are never read: no predicate, no branch)
+      *reinterpret_cast<f16x4*>(dst0 + u * RPS * 16) = eh;
+      if constexpr (TERMS == 3) *reinterpret_cast<f16x4*>(dst0 + u * RPS * 16 + XIMG) = el;
     }
   };
   // ---- weight slices by LDS-DMA: slice (chunk, tap) = NBLK pieces of 1 KiB, contiguous in the packed image.
@@ -187,11 +232,11 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
   const uint4* Wg = reinterpret_cast<const uint4*>(a.wh);
   int dc = 0, dt = 0;
   auto dma_next = [&](int slot) {
-    const size_t src = (((size_t)dc * K + dt) * nmt + (size_t)cb * MTB) * 128;   // uint4 units (2 KiB per m-tile)
+    const size_t src = (G16_DIAG & 32) ? 0 : (((size_t)dc * K + dt) * nmt + (size_t)cb * MTB) * 128;   // uint4 units (2 KiB per m-tile)
 #pragma unroll
     for (int u = 0; u < NBW; ++u) {
       const int blk = u * NWV + wave;
-      if (NBLK % NWV == 0 || blk < NBLK) {
+      if ((NBLK % NWV == 0 || blk < NBLK) && (G16_DIAG & 2) == 0) {
         const uint4* gp = Wg + src + (size_t)blk * 64 + lane;
         char* lp = Rg + slot * SLOT + blk * 1024;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
@@ -200,25 +245,14 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
     }
     if (++dt == K) { dt = 0; ++dc; }
   };
-  // pieces of a slice issued by THIS wave (the counted waits below need the exact number)
-  int my_pieces = 0;
-#pragma unroll
-  for (int u = 0; u < NBW; ++u) my_pieces += (NBLK % NWV == 0 || u * NWV + wave < NBLK) ? 1 : 0;
+  // (a wave that copies no piece of a slice -- NBLK < NWV -- has nothing of its own to wait for there)
+  const bool has_pieces = NBLK % NWV == 0 || wave < NBLK;
 
-  // ---- fragments
-  const int xb_lane = (lane >> 4) * PL + (wn * NW * 16 + (lane & 15)) * 16;
-  const int wa_lane = lane * 16 + wm * MW * 2048;
-  f16x8 Ah[MW], Al[MW], Bh[2], Bl[2];
-  auto loadA = [&](int i, int slot) {
-    const char* p = Rg + slot * SLOT + wa_lane + i * 2048;
-    Ah[i] = *reinterpret_cast<const f16x8*>(p);
-    if constexpr (TERMS == 3) Al[i] = *reinterpret_cast<const f16x8*>(p + 1024);
-  };
-  auto loadB = [&](int which, int buf, int tap, int j) {
-    const char* p = Xw + buf * XBUF + xb_lane + (tap * a.dil + j * 16) * 16;
-    Bh[which] = *reinterpret_cast<const f16x8*>(p);
-    if constexpr (TERMS == 3) Bl[which] = *reinterpret_cast<const f16x8*>(p + XIMG);
-  };
+  // ---- fragments: asm reads with immediate offsets off two per-step base addresses
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  const unsigned xb_lane = lds0 + (lane >> 4) * PL + (wn * NW * 16 + (lane & 15)) * 16;
+  const unsigned wa_lane = lds0 + 2 * XBUF + lane * 16 + wm * MW * 2048;
+  f16x8 Ah[MW], Al[MW], Bh[NW], Bl[NW];
 
   // accumulators start at the bias: a lane holds rows 4 (l >> 4) .. + 3 of its m-tiles
   f32x4 hh[MW][NW], cr[MW][NW];
@@ -232,63 +266,85 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
     for (int j = 0; j < NW; ++j) { hh[i][j] = bv; cr[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   }
 
-  // ---- prologue: window chunk 0, slices 0 and 1 (then 2 behind the first barrier)
+  // ---- prologue: window chunk 0, slices 0 .. 2
   x_issue(0);
   dma_next(0);
   if (S > 1) dma_next(1);
-  x_write(0);                       // (the compiler waits for the window loads here)
-  int xl_a = 0, xl_b = 0;           // window loads issued behind slice s+1 / s+2 (still counted by vmcnt)
-  if (nch > 1) { x_issue(1); xl_a = 1; }
-  g16_vm_wait(xl_a * NL);           // slices 0 and 1 have landed
-  G16_BARRIER();
   if (S > 2) dma_next(2);
-#pragma unroll
-  for (int i = 0; i < MW; ++i) loadA(i, 0);
-  loadB(0, 0, 0, 0);
+  x_write(0);                       // (the compiler waits for the window loads here)
+  int xl_a = 0, xl_b = 0;           // window loads issued in the previous / in this MEM phase (still counted by vmcnt)
+  if (nch > 1) { x_issue(1); xl_b = 1; }
+  g16_vm_wait<NBW, NL>(false, xl_b);   // slices 0 .. 2 have landed
+  G16_BARRIER();
+  // PING-PONG.  Waves w and w + NWV/2 share a SIMD.  Each wave alternates a MEM phase (all fragments of one step
+  // into registers, its LDS-DMA pieces, window staging) with an MFMA phase (the step's MW*NW*3 MFMAs back to back),
+  // one barrier between phases; the second half of the block runs one phase behind the first (it starts with a
+  // barrier), so a SIMD's matrix core always has one wave multiplying while its partner does the memory work.
+  if (wave >= NWV / 2) G16_BARRIER();
 
   int chunk = 0, tap = 0, slot = 0;   // of the current step
   for (int s = 0; s < S; ++s) {
     const bool last_tap = tap == K - 1;
     const int chunk_n = last_tap ? chunk + 1 : chunk, tap_n = last_tap ? 0 : tap + 1;   // of step s + 1
-    const bool more = s + 1 < S;
-    const bool wr_step = last_tap && chunk + 1 < nch;      // window chunk + 1 is written in this step
-    const int buf = NXB == 2 ? (chunk & 1) : 0, buf_n = NXB == 2 ? (chunk_n & 1) : 0;
-    const int slot_n = slot == NS - 1 ? 0 : slot + 1;
-#pragma unroll
-    for (int j = 0; j < NW; ++j) {
-      if (j == NW - 1 && more) {
-        // ---- the step's barrier point: everything of slice s is in registers
-        if (wr_step) {
-          if constexpr (NXB == 1) G16_BARRIER();            // every wave is done reading the window
-          x_write(buf_n);
-        }
-        // slice s + 1 has landed.  Issued after it: slice s + 2 and the window loads of the last two barrier points
-        g16_vm_wait((s + 2 < S ? my_pieces : 0) + (xl_a + xl_b) * NL);
-        G16_BARRIER();
-        if (s + 3 < S) dma_next(slot);                      // into the slot slice s just left
-        xl_a = xl_b;
-        xl_b = 0;
-        if (wr_step && chunk + 2 < nch) { x_issue(chunk + 2); xl_b = 1; }
+    const bool wr_step = last_tap && chunk + 1 < nch;      // window chunk + 1 is staged in this step's MEM phase
+    // ================= MEM phase of step s =================
+    {
+      const unsigned b_cur = xb_lane + (chunk & 1) * XBUF + tap * a.dil * 16;
+      const unsigned a_cur = wa_lane + slot * SLOT;
+      g16_for<NW>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        Bh[j] = g16_lds_read<j * 256>(b_cur);
+        if constexpr (TERMS == 3) Bl[j] = g16_lds_read<j * 256 + XIMG>(b_cur);
+      });
+      g16_for<MW>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        Ah[i] = g16_lds_read<i * 2048>(a_cur);
+        if constexpr (TERMS == 3) Al[i] = g16_lds_read<i * 2048 + 1024>(a_cur);
+      });
+      xl_a = xl_b;
+      xl_b = 0;
+      if (wr_step) {
+        x_write(chunk_n & 1);                               // the other window buffer: last read a chunk ago
+        if (chunk + 2 < nch) { x_issue(chunk + 2); xl_b = 1; }
       }
-      // B fragment of the next sub-step (of the next step's first sub-step at the end)
-      if (j + 1 < NW) loadB((j + 1) & 1, buf, tap, j + 1);
-      else if (more) loadB((j + 1) & 1, buf_n, tap_n, 0);
-#pragma unroll
-      for (int i = 0; i < MW; ++i) {
-        hh[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[i], Bh[j & 1], hh[i][j], 0, 0, 0);
-        if constexpr (TERMS == 3) {
-          cr[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al[i], Bh[j & 1], cr[i][j], 0, 0, 0);
-          cr[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[i], Bl[j & 1], cr[i][j], 0, 0, 0);
-        }
-        if (j == NW - 1 && more) loadA(i, slot_n);          // in place: the A fragments of slice s + 1
+      if (s + 3 < S) dma_next(slot == 0 ? NS - 1 : slot - 1);   // slice s + 3 into the slot slice s - 1 left
+      // my pieces of slice s + 1 have landed: issued after them are slices s + 2, s + 3 and the window loads of this
+      // and the previous MEM phase
+      if (s + 1 < S) {
+        const int behind = (s + 2 < S ? 1 : 0) + (s + 3 < S ? 1 : 0);
+        if (!has_pieces || behind == 0) g16_vm_wait<0, NL>(false, xl_a + xl_b);
+        else if (behind == 1) g16_vm_wait<NBW, NL>(true, xl_a + xl_b);
+        else g16_vm_wait<2 * NBW, NL>(true, xl_a + xl_b);
       }
+      G16_BARRIER();                                        // (lgkmcnt(0): the fragments are here)
     }
+    // ================= MFMA phase of step s =================
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    g16_for<NW>([&](auto J) {
+      constexpr int j = decltype(J)::value;
+      g16_for<MW>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        hh[i][j] = G16_MFMA(Ah[i], Bh[j], hh[i][j]);
+        if constexpr (TERMS == 3) {
+          cr[i][j] = G16_MFMA(Al[i], Bh[j], cr[i][j]);
+          cr[i][j] = G16_MFMA(Ah[i], Bl[j], cr[i][j]);
+        }
+      });
+    });
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    G16_BARRIER();
     chunk = chunk_n;
     tap = tap_n;
-    slot = slot_n;
+    slot = slot == NS - 1 ? 0 : slot + 1;
   }
+  // (the first half of the block has executed one barrier fewer: it goes straight to its epilogue, which overlaps
+  // the second half's last MFMA phase; a wave that has ended no longer takes part in the barrier)
 
-  // ---- epilogue: lane = 4 consecutive rows (channels) of one time column: 16-byte accesses
+  // ---- epilogue: lane = 4 consecutive rows (channels) of one time column: 16-byte accesses.  All residual /
+  //      accumulate operands of the wave's tiles are requested first (the fragment registers are dead now).
+  int oo[MW][NW], orr[MW][NW];
 #pragma unroll
   for (int i = 0; i < MW; ++i) {
     const int row = ((cb * MTB + wm * MW + i) << 4) + 4 * (lane >> 4);
@@ -297,26 +353,52 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
     for (int j = 0; j < NW; ++j) {
       const int t = t0 + (wn * NW + j) * 16 + (lane & 15);
       const int n = a.phases * t + ph - a.ups_p;            // output row (< 0 or >= T_store: dropped by the descriptor)
-      const bool in_t = t < a.Nq;
-      const int oo = in_t ? n * a.o_ts * 4 + co * 4 : G16_OOR;
-      f32x4 v;
-      if constexpr (TERMS == 3) v = hh[i][j] + cr[i][j] * (1.f / 2048.f);
-      else v = hh[i][j];
-      if (a.res) v += g16_as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(rr_, in_t ? n * a.r_ts * 4 + co * 4 : G16_OOR, 0, 0));
-      if (a.acc_prev) v += g16_as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(ro, oo, 0, 0));
-      if (a.div != 1.f) v /= a.div;
-      __builtin_amdgcn_raw_buffer_store_b128(g16_as_u32x4(v), ro, oo, 0, 0);
+      const bool in_t = t < a.Nq && (G16_DIAG & 8) == 0;
+      oo[i][j] = in_t ? n * a.o_ts * 4 + co * 4 : G16_OOR;
+      orr[i][j] = in_t ? n * a.r_ts * 4 + co * 4 : G16_OOR;
     }
   }
+  u32x4 rv[MW][NW];
+  if (a.res) {
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+      for (int j = 0; j < NW; ++j) rv[i][j] = __builtin_amdgcn_raw_buffer_load_b128(rr_, orr[i][j], 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < MW; ++i)
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      if constexpr (TERMS == 3) hh[i][j] += cr[i][j] * (1.f / 2048.f);
+      if (a.res) hh[i][j] += g16_as_f32x4(rv[i][j]);
+    }
+  if (a.acc_prev) {
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+      for (int j = 0; j < NW; ++j) rv[i][j] = __builtin_amdgcn_raw_buffer_load_b128(ro, oo[i][j], 0, 0);
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+      for (int j = 0; j < NW; ++j) hh[i][j] += g16_as_f32x4(rv[i][j]);
+  }
+#pragma unroll
+  for (int i = 0; i < MW; ++i)
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      f32x4 v = hh[i][j];
+      if (a.div != 1.f) v /= a.div;
+      __builtin_amdgcn_raw_buffer_store_b128(g16_as_u32x4(v), ro, oo[i][j], 0, 0);
+    }
 }
 
-template <int MW, int NW, int WM, int WN, int NXB, int TERMS>
+template <int MW, int NW, int WM, int WN, int TERMS>
 static hipError_t launch_g16_tile(const ClConvArgs& a, int B, hipStream_t s) {
   constexpr int BT = 16 * NW * WN, MTB = MW * WM;
-  constexpr size_t lds = (size_t)NXB * 2 * 4 * (BT + G16_HALO) * 16 + (size_t)3 * MTB * 2048;
+  constexpr size_t lds = (size_t)2 * 2 * 4 * (BT + G16_HALO) * 16 + (size_t)4 * MTB * 2048;
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
-  auto kern = g16_conv<MW, NW, WM, WN, NXB, TERMS>;
+  auto kern = g16_conv<MW, NW, WM, WN, TERMS>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -335,17 +417,25 @@ hipError_t launch_g16_conv(const ClConvArgs& a, int B, hipStream_t s) {
       (reinterpret_cast<uintptr_t>(a.out) & 15))
     return hipErrorInvalidValue;
   const int rows = a.phases * a.Cout;
-  // <MW, NW, WM, WN, NXB, TERMS>
+  // <MW, NW, WM, WN, TERMS>
   if (a.terms == 1) {
-    if (rows % 128 == 0) return launch_g16_tile<4, 4, 2, 4, 2, 1>(a, B, s);
-    if (rows % 64 == 0) return launch_g16_tile<4, 2, 1, 8, 1, 1>(a, B, s);
-    if (rows % 32 == 0) return launch_g16_tile<2, 2, 1, 8, 1, 1>(a, B, s);
+    if (rows % 128 == 0) return launch_g16_tile<4, 4, 2, 4, 1>(a, B, s);
+    if (rows % 64 == 0) return launch_g16_tile<4, 2, 1, 8, 1>(a, B, s);
+    if (rows % 32 == 0) return launch_g16_tile<2, 2, 1, 8, 1>(a, B, s);
     return hipErrorInvalidValue;
   }
-  if (rows % 128 == 0) return launch_g16_tile<4, 4, 2, 4, 2, 3>(a, B, s);   // 128 rows x 256 columns, one block per CU
-  if (rows % 64 == 0) return launch_g16_tile<4, 2, 1, 8, 1, 3>(a, B, s);    //  64 rows x 256 columns, two blocks per CU
-  if (rows % 32 == 0) return launch_g16_tile<2, 2, 1, 8, 1, 3>(a, B, s);    //  32 rows x 256 columns
+  if (rows % 128 == 0) return launch_g16_tile<4, 4, 2, 4, 3>(a, B, s);   // 128 rows x 256 columns, one block per CU
+  if (rows % 64 == 0) return launch_g16_tile<4, 2, 1, 8, 3>(a, B, s);    //  64 rows x 256 columns, two blocks per CU
+  if (rows % 32 == 0) return launch_g16_tile<2, 2, 1, 8, 3>(a, B, s);    //  32 rows x 256 columns
   return hipErrorInvalidValue;
+}
+
+// pair kernel: a wave copies 0, 1 or 2 pieces of a slice (partial last slices of a chunk)
+template <int NL>
+__device__ __forceinline__ void g16_pair_wait(int pieces, int groups) {
+  if (pieces == 0) g16_vm_wait<0, NL>(false, groups);
+  else if (pieces == 1) g16_vm_wait<1, NL>(true, groups);
+  else g16_vm_wait<2, NL>(true, groups);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -357,13 +447,13 @@ hipError_t launch_g16_conv(const ClConvArgs& a, int B, hipStream_t s) {
 // The arithmetic per output (chunk-major, tap-minor, HH / CROSS / CROSS per step, bias in the accumulator) is that of
 // g16_conv, so the result is bit-identical to the two-launch path.
 //   NCH = C / 32 (1 or 2); G = taps per ring slot.
-template <int NCH, int G, int TERMS>
-__global__ void __launch_bounds__(512, 4) g16_pair(ClPairArgs a) {
-  constexpr int MW = 2 * NCH, NW = 2, NWV = 8, C = 32 * NCH;
-  constexpr int BT = 256, WR = BT + G16_HALO, PL = WR * 16, XIMG = 4 * PL, XBUF = 2 * XIMG;
+template <int NCH, int G, int TERMS, int NWV>
+__global__ void __launch_bounds__(64 * NWV, 4) g16_pair(ClPairArgs a) {
+  constexpr int MW = 2 * NCH, NW = 2, C = 32 * NCH;
+  constexpr int BT = 32 * NWV, WR = BT + G16_HALO, PL = WR * 16, XIMG = 4 * PL, XBUF = 2 * XIMG;
   constexpr int TAPB = MW * 2048;               // bytes of one tap in a ring slot
   constexpr int SLOT = G * TAPB;
-  constexpr int NS = 3, RPS = 64, NL = (WR + RPS - 1) / RPS;
+  constexpr int NS = 3, RPS = 8 * NWV, NL = (WR + RPS - 1) / RPS;
   constexpr int NPT = 2 * MW;                   // 1 KiB pieces per tap
   constexpr int NBWMAX = (G * NPT + NWV - 1) / NWV;
   constexpr bool EARLY_RES = NCH == 1 && TERMS == 3;
@@ -404,7 +494,8 @@ __global__ void __launch_bounds__(512, 4) g16_pair(ClPairArgs a) {
 #pragma unroll
     for (int u = 0; u < NL; ++u) {
       const bool in = (u + 1) * RPS <= BT || row_s + u * RPS < xrows;
-      sv[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, in ? st_voff + (base + u * RPS * C * 4) : G16_OOR, 0, 0);
+      sv[u] = (G16_DIAG & 16) ? u32x4{1u, 2u, 3u, 4u}
+                              : __builtin_amdgcn_raw_buffer_load_b128(rx, in ? st_voff + (base + u * RPS * C * 4) : G16_OOR, 0, 0);
     }
   };
   auto x_write = [&]() {
@@ -413,10 +504,8 @@ __global__ void __launch_bounds__(512, 4) g16_pair(ClPairArgs a) {
     for (int u = 0; u < NL; ++u) {
       f16x4 eh, el;
       g16_split4(g16_as_f32x4(sv[u]), slope, true, eh, el);
-      if ((u + 1) * RPS <= BT || row_s + u * RPS < xrows) {
-        *reinterpret_cast<f16x4*>(dst0 + u * RPS * 16) = eh;
-        if constexpr (TERMS == 3) *reinterpret_cast<f16x4*>(dst0 + u * RPS * 16 + XIMG) = el;
-      }
+      *reinterpret_cast<f16x4*>(dst0 + u * RPS * 16) = eh;
+      if constexpr (TERMS == 3) *reinterpret_cast<f16x4*>(dst0 + u * RPS * 16 + XIMG) = el;
     }
   };
 
@@ -427,12 +516,12 @@ __global__ void __launch_bounds__(512, 4) g16_pair(ClPairArgs a) {
     const uint4* Wg = reinterpret_cast<const uint4*>(dv ? a.w2h : a.w1h);
     const int tap0 = dsl * G;
     const int pieces = ((K - tap0) < G ? (K - tap0) : G) * NPT;
-    const size_t src = ((size_t)dc * K + tap0) * MW * 128;        // uint4 units
+    const size_t src = (G16_DIAG & 32) ? 0 : ((size_t)dc * K + tap0) * MW * 128;        // uint4 units
     int mine = 0;
 #pragma unroll
     for (int u = 0; u < NBWMAX; ++u) {
       const int p = u * NWV + wave;
-      if (p < pieces) {
+      if (p < pieces && (G16_DIAG & 2) == 0) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wg + src + (size_t)p * 64 + lane),
                                          (__attribute__((address_space(3))) void*)(Rg + slot * SLOT + p * 1024), 16, 0, 0);
         ++mine;
@@ -464,10 +553,10 @@ __global__ void __launch_bounds__(512, 4) g16_pair(ClPairArgs a) {
         if constexpr (TERMS == 3) Al = *reinterpret_cast<const f16x8*>(pa + i * 2048 + 1024);
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
-          hh[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bh[j], hh[i][j], 0, 0, 0);
+          hh[i][j] = G16_MFMA(Ah, Bh[j], hh[i][j]);
           if constexpr (TERMS == 3) {
-            cr[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bh[j], cr[i][j], 0, 0, 0);
-            cr[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bl[j], cr[i][j], 0, 0, 0);
+            cr[i][j] = G16_MFMA(Al, Bh[j], cr[i][j]);
+            cr[i][j] = G16_MFMA(Ah, Bl[j], cr[i][j]);
           }
         }
       }
@@ -511,7 +600,7 @@ __global__ void __launch_bounds__(512, 4) g16_pair(ClPairArgs a) {
   int chunk = 0, sl = 0;
   for (int s = 0; s < S1; ++s) {
     // slice s has landed: issued after it are slice s + 1 and the window loads of the last two steps
-    g16_vm_wait(pc_nxt + (xl_a + xl_b) * NL);
+    g16_pair_wait<NL>(pc_nxt, xl_a + xl_b);
     G16_BARRIER();                                   // slice s (and a freshly written window) visible to all
     pc_cur = pc_nxt;
     pc_nxt = s + 2 < S ? dma_next(slot == 0 ? 2 : slot - 1) : 0;     // slot of slice s - 1
@@ -568,7 +657,7 @@ __global__ void __launch_bounds__(512, 4) g16_pair(ClPairArgs a) {
       }
     for (int sl2 = 0; sl2 < ns; ++sl2) {
       const int s = S1 + c2 * ns + sl2;
-      g16_vm_wait(pc_nxt + (xl_a + xl_b) * NL);
+      g16_pair_wait<NL>(pc_nxt, xl_a + xl_b);
       G16_BARRIER();
       pc_cur = pc_nxt;
       pc_nxt = s + 2 < S ? dma_next(slot == 0 ? 2 : slot - 1) : 0;
@@ -598,22 +687,23 @@ __global__ void __launch_bounds__(512, 4) g16_pair(ClPairArgs a) {
     }
 }
 
-template <int NCH, int G, int TERMS>
+template <int NCH, int G, int TERMS, int NWV>
 static hipError_t launch_g16_pair_tile(ClPairArgs a, int B, hipStream_t s) {
-  constexpr size_t lds = (size_t)2 * 4 * (256 + G16_HALO) * 16 + (size_t)3 * G * 2 * NCH * 2048;
-  static_assert(lds <= 80 * 1024, "two blocks per CU");
+  constexpr int BT = 32 * NWV;
+  constexpr size_t lds = (size_t)2 * 4 * (BT + G16_HALO) * 16 + (size_t)3 * G * 2 * NCH * 2048;
+  static_assert(lds <= (NWV == 8 ? 80 : 160) * 1024, "two 8-wave blocks or one 16-wave block per CU");
   static bool attr_set = false;
-  auto kern = g16_pair<NCH, G, TERMS>;
+  auto kern = g16_pair<NCH, G, TERMS, NWV>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  const int R2 = 256 - (a.K - 1);
+  const int R2 = BT - (a.K - 1);
   a.tiles = (a.T + R2 - 1) / R2;
   const long n = (long)a.tiles * B;
   if (n <= 0 || n > 0x7fffffffL) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(512), lds, s, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(64 * NWV), lds, s, a);
   return hipGetLastError();
 }
 
@@ -625,8 +715,14 @@ hipError_t launch_g16_pair(const ClPairArgs& a, int B, hipStream_t s) {
   if (!g16_pair_supported(a.C, a.K, a.dil) || a.T <= 0 || B <= 0 || (a.x_bs & 3) || (a.o_bs & 3) ||
       (reinterpret_cast<uintptr_t>(a.x) & 15) || (reinterpret_cast<uintptr_t>(a.out) & 15) || a.x == a.out)
     return hipErrorInvalidValue;
-  if (a.terms == 1) return a.C == 32 ? launch_g16_pair_tile<1, 2, 1>(a, B, s) : launch_g16_pair_tile<2, 1, 1>(a, B, s);
-  return a.C == 32 ? launch_g16_pair_tile<1, 2, 3>(a, B, s) : launch_g16_pair_tile<2, 1, 3>(a, B, s);
+  // block shape: 16 waves x 32 columns (one block per CU: ONE weight ring per CU, half the LDS-DMA pieces and L2
+  // reads of two 8-wave blocks) or 8 waves (two blocks per CU); VSP_PAIR_WAVES=8 selects the latter
+  static int nwv = -1;
+  if (nwv < 0) { const char* e = getenv("VSP_PAIR_WAVES"); nwv = e ? atoi(e) : 8; }
+  if (a.terms == 1)
+    return a.C == 32 ? launch_g16_pair_tile<1, 2, 1, 8>(a, B, s) : launch_g16_pair_tile<2, 1, 1, 8>(a, B, s);
+  if (nwv == 8) return a.C == 32 ? launch_g16_pair_tile<1, 2, 3, 8>(a, B, s) : launch_g16_pair_tile<2, 1, 3, 8>(a, B, s);
+  return a.C == 32 ? launch_g16_pair_tile<1, 2, 3, 16>(a, B, s) : launch_g16_pair_tile<2, 1, 3, 16>(a, B, s);
 }
 
 }  // namespace vsp
