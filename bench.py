@@ -3,60 +3,86 @@
 SynthesizerTrn.infer on the BASELINE.json headline workload (C3: a 64-utterance mixed zh/ja
 batch of ~5 s utterances, phoneme/duration/F0/energy/noise supplied), one process per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C2|C3|C4|C5] [--controls all|duration|none]
 
-A step = one full infer() of the rank's 64-utterance batch with all inputs resident in HBM.
-For N > 1 every rank runs its own 64-utterance shard (weak scaling, seeds 103 + rank) padded to
-the GLOBAL frame count (one int all-reduce MAX, SURVEY gotcha G6), and the step ends with the
-gather of the waveforms on rank 0 over RCCL -- the exchange the north star names.  Packed
-weights are broadcast from rank 0 once, before timing.  value = valid samples of all ranks / time.
+`--gpus N` with N > 1 launches itself: the parent process (which never touches a GPU) starts
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same args>`
+and relays rank 0's single JSON line; under torch.distributed.run (RANK / WORLD_SIZE in the environment) it is a
+rank.  Workloads:
+  C3 (default)  every rank runs its own 64-utterance shard (weak scaling, seeds 103 + rank);
+  C4            ONE global batch of 256 utterances, rank r synthesises its `shard_range` slice (32 each at 8 GPUs;
+                strong scaling) through `sharding.infer_sharded`;
+both pad to the GLOBAL frame count (one int all-reduce MAX, SURVEY gotcha G6), broadcast the packed weights from
+rank 0 over RCCL once before timing, and end every step with the gather of the waveforms on rank 0 -- the
+exchange the north star names.  value = valid samples of all ranks / max-over-ranks time.
+
+A step = one full infer() with all inputs resident in HBM.  The headline is timed with profiling OFF; the
+per-kernel-class event timing behind `roofline` comes from a second, untimed pass of `--profile-steps` steps.
+At N = 1 rank 0 then times the parity-pinned CPU oracle on a bounded sample of the same batch (`cpu_baseline`)
+and checks the GPU waveform of those utterances against it (`parity`).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-MEASURED_F16_MFMA_CEILING_TFLOPS = 1550.0   # tools/micro/mfma_lds_loop.hip on MI355X, pseudo-random operands
+# tools/micro/mfma_shape.hip on MI355X, pseudo-random operands, v_mfma_f32_16x16x32_f16 fed from LDS, barrier per 64-deep step
+MEASURED_F16_MFMA_CEILING_TFLOPS = 1844.0
 PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense f16/bf16 MFMA
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
 ALG_BYTES_PER_SAMPLE = 13045     # SURVEY.md 8(d), fp32 end-to-end layer-boundary traffic
 ALG_FLOPS_PER_SAMPLE = 1.641e6   # SURVEY.md 8(d)
 
-
 WL_TEXT = {"C1": "zh utterance (~5 s)", "C2": "zh utterances (~5 s each)", "C3": "mixed zh/ja utterances (~5 s each)",
-           "C4": "mixed zh/ja utterances (~5 s each)", "C5": "long-form utterance (60 s, 5168 frames)"}
+           "C4": "mixed zh/ja utterances (~5 s each), one global batch sharded over the ranks",
+           "C5": "long-form utterance (60 s, 5168 frames)"}
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=3)
     p.add_argument("--warmup", type=int, default=1)
     p.add_argument("--workload", default="C3")
-    p.add_argument("--batch", type=int, default=None, help="override utterances per GPU (debug)")
+    p.add_argument("--batch", type=int, default=None,
+                   help="override the batch: utterances per GPU (C3 and the other per-rank workloads) or of the GLOBAL batch (C4)")
+    p.add_argument("--controls", default="all", choices=["all", "duration", "none"],
+                   help="which control tensors are supplied: all (headline), duration only (F0 / energy predicted), "
+                        "none (every predictor of reference models.py:681-708 runs)")
+    p.add_argument("--profile-steps", type=int, default=2, help="untimed steps with per-launch events (roofline)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample", type=int, default=16, help="utterances of the batch timed on the CPU oracle")
-    return p.parse_args()
+    return p.parse_args(argv)
 
 
-def cpu_baseline(sd, dims, batch, n_utt):
-    """The parity-pinned CPU restatement (oracle/, kind 'port') timed on the host cores on the
-    first n_utt utterances of the same batch."""
-    from oracle.vispeech_oracle import Oracle
-    # threads actually usable by this process (cgroup/affinity), capped: torch's CPU convolutions
-    # stop scaling (and collapse under oversubscription) far below the 256 hardware threads of the host
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as CHILD processes (this
+    process has not touched the GPU and never will) and relay their output."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.run(cmd, env=env)
+    return p.returncode
+
+
+def usable_cores() -> int:
+    """Threads actually usable by this process (cgroup / affinity), capped: torch's CPU convolutions stop scaling
+    (and collapse under oversubscription) far below the 256 hardware threads of the host."""
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -67,41 +93,76 @@ def cpu_baseline(sd, dims, batch, n_utt):
             avail = min(avail, max(1, int(q) // int(per)))
     except Exception:
         pass
-    cores = max(1, min(avail, 32))
+    return max(1, min(avail, 32))
+
+
+def cpu_baseline_and_parity(sd, dims, batch, n_utt, controls, tf_global, noise_global, gpu_out):
+    """The parity-pinned CPU restatement (oracle/, kind 'port') on the first n_utt utterances of the same batch,
+    padded exactly like the GPU run (global T_p and T_f, gotchas G5 / G6) so that its waveform is THE reference for
+    the GPU output of those utterances.  Returns (cpu_baseline, parity)."""
+    import numpy as np
+    import torch
+    from oracle.vispeech_oracle import Oracle
+    cores = usable_cores()
     torch.set_num_threads(cores)
     orc = Oracle(sd, dims)
     sl = slice(0, n_utt)
-    tp = int(batch["lengths"][sl].max())
-    tf = int(batch["frame_lengths"][sl].max())
-    kw = dict(noise=batch["noise"][sl, :, :tf], noise_scale=0.667, duration_control=batch["duration"][sl, :tp],
-              pitch_control=batch["f0"][sl, :tp], energy_control=batch["energy"][sl, :tp])
+    kw = dict(noise_scale=0.667)
+    if controls in ("all", "duration"):
+        kw["duration_control"] = batch["duration"][sl]
+    if controls == "all":
+        kw["pitch_control"] = batch["f0"][sl]
+        kw["energy_control"] = batch["energy"][sl]
     # tiny warm-up (thread pool, mkldnn primitives)
     orc.infer(batch["phonemes"][:1, :4], np.array([4]), batch["sid"][:1], noise=batch["noise"][:1, :, :8],
               noise_scale=0.667, duration_control=np.full((1, 4), 2.0, dtype=np.float32),
               pitch_control=batch["f0"][:1, :4], energy_control=batch["energy"][:1, :4])
     t0 = time.perf_counter()
-    orc.infer(batch["phonemes"][sl, :tp], batch["lengths"][sl], batch["sid"][sl], **kw)
+    ref = orc.infer(batch["phonemes"][sl], batch["lengths"][sl], batch["sid"][sl], noise=noise_global[sl],
+                    t_f=tf_global, **kw)
     dt = time.perf_counter() - t0
-    samples = 512 * int(batch["frame_lengths"][sl].sum())
-    return {"value": samples / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"first {n_utt} utterances of the same batch ({samples} valid samples, {dt:.1f} s, "
-                      f"oracle/vispeech_oracle.py on torch CPU fp32, {cores} threads)",
+    frames = np.asarray(gpu_out["frames"][sl], dtype=np.int64)
+    samples = 512 * int(frames.sum())
+    base = {"value": samples / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"first {n_utt} utterances of the same batch, padded to the batch's {tf_global} frames "
+                      f"({samples} valid samples, {dt:.1f} s, oracle/vispeech_oracle.py on torch CPU fp32, {cores} threads)",
             "rtf": dt / (samples / 44100.0)}
+    # parity of the very utterances the timed run produced (outside the timed region)
+    ro = ref["o"].numpy()
+    go = gpu_out["o"][sl].cpu().numpy()
+    par = {"utterances": int(n_utt), "padded_frames": int(tf_global), "tolerance": 1e-4}
+    rd = np.asarray(ref["duration"]).reshape(n_utt, -1)
+    gd = gpu_out["duration"][sl].cpu().numpy().reshape(n_utt, -1)
+    par["duration_mismatches"] = int((rd != gd).sum())
+    if go.shape == ro.shape and par["duration_mismatches"] == 0:
+        par["max_rel_err"] = float(np.abs(go - ro).max() / max(np.abs(ro).max(), 1e-30))
+        gz, rz = gpu_out["z"][sl].cpu().numpy(), ref["z"].numpy()
+        par["z_max_rel_err"] = float(np.abs(gz - rz).max() / max(np.abs(rz).max(), 1e-30))
+        par["ok"] = bool(par["max_rel_err"] <= par["tolerance"])
+    else:
+        par["max_rel_err"] = None
+        par["ok"] = False
+        par["note"] = f"shapes {go.shape} vs {ro.shape}: predicted durations differ, waveforms not comparable"
+    return base, par
 
 
 def main():
     args = parse()
+    if "RANK" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
+    import numpy as np
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch.distributed as dist
-    from vispeech_amd import config as vcfg
+    from vispeech_amd import _lib, config as vcfg
     from vispeech_amd.models import SynthesizerTrn
     from vispeech_amd.schema import ModelDims
+    from vispeech_amd.sharding import broadcast_weights, gather_batch, global_max, shard_range
     from vispeech_amd.synth import WORKLOADS, synth_batch, synth_state_dict
 
     # one process per GPU; VSP_BENCH_BACKEND=gloo (test hook) lets several ranks share one GPU to exercise the
@@ -118,44 +179,67 @@ def main():
             dist.init_process_group(backend)
 
     dims = ModelDims()
-    hps = vcfg.default_hparams()
-    a, kw = vcfg.synthesizer_args(hps)
+    a, kw = vcfg.synthesizer_args(vcfg.default_hparams())
     net = SynthesizerTrn(*a, device=dev, **kw).eval()
-    from vispeech_amd.sharding import broadcast_weights, gather_batch, global_max
     sd = synth_state_dict(dims, seed=1234, infer_only=True) if rank == 0 or world == 1 else None
     if world == 1:
         net.load_state_dict(sd)
     else:
-        # RCCL weight broadcast: rank 0 packs, everyone else adopts the broadcast arena
+        # RCCL weight broadcast: rank 0 packs, everyone else adopts the broadcast arena and checks its header
         broadcast_weights(net._engine, sd, src=0)
         torch.cuda.synchronize()
+    eng = net._engine
 
+    # ---- the batch.  C4: one global batch, this rank's slice; otherwise one batch per rank
     wl = dict(WORKLOADS[args.workload])
-    wl["seed"] = wl["seed"] + rank
+    sharded_global = args.workload == "C4"
     if args.batch:
         wl["batch"] = args.batch
+    if not sharded_global:
+        wl["seed"] = wl["seed"] + rank
     batch = synth_batch(**wl)
-    B = int(batch["phonemes"].shape[0])
+    B_all = int(batch["phonemes"].shape[0])
+    lo, hi = shard_range(B_all, rank, world) if sharded_global else (0, B_all)
+    sl = slice(lo, hi)
+    B = hi - lo
     t = lambda x: torch.from_numpy(np.asarray(x)).to(dev)
-    ph, ln, sid = t(batch["phonemes"]), t(batch["lengths"]), t(batch["sid"])
-    dur, f0, en = t(batch["duration"]), t(batch["f0"]), t(batch["energy"])
-    tf_local = int(batch["frame_lengths"].max())
-    valid_samples = 512 * int(batch["frame_lengths"].sum())
+    ph, ln, sid = t(batch["phonemes"][sl]), t(batch["lengths"][sl]), t(batch["sid"][sl])
+    ctl = {}
+    if args.controls in ("all", "duration"):
+        ctl["duration_control"] = t(batch["duration"][sl])
+    if args.controls == "all":
+        ctl["pitch_control"] = t(batch["f0"][sl])
+        ctl["energy_control"] = t(batch["energy"][sl])
+    # frame counts: known from the supplied durations, else from one untimed encode (the predictor decides)
+    if "duration_control" in ctl:
+        frames_local = batch["frame_lengths"][sl].astype(np.int64)
+    else:
+        enc = eng.encode(ph, ln, sid)
+        frames_local = np.asarray(eng.frame_lengths_host(enc["frame_lengths"])[0], dtype=np.int64)
+    tf_local = int(frames_local.max()) if B else 0
     tf_global = global_max(tf_local, dev)
-    noise = torch.zeros(B, dims.inter_channels, tf_global, dtype=torch.float32, device=dev)
-    noise[:, :, :tf_local] = t(batch["noise"])
+    valid_samples = 512 * int(frames_local.sum())
+    r = np.random.Generator(np.random.PCG64(wl["seed"] * 7919 + 13))
+    noise_np = np.zeros((B_all if sharded_global else B, dims.inter_channels, tf_global), dtype=np.float32)
+    if "duration_control" in ctl:
+        noise_np[:, :, :batch["noise"].shape[2]] = batch["noise"]
+    else:
+        noise_np[:] = r.standard_normal(noise_np.shape, dtype=np.float32)
+    noise = t(noise_np[sl] if sharded_global else noise_np)
+
+    last = {}
 
     def step():
-        o, *_ = net.infer(ph, ln, sid=sid, noise_scale=0.667, duration_control=dur, pitch_control=f0,
-                          energy_control=en, noise=noise, t_f=tf_global)
+        o, x_mask, (z, z_p, m_p, logs_p), duration, f0, energy = net.infer(
+            ph, ln, sid=sid, noise_scale=0.667, noise=noise, t_f=tf_global, **ctl)
         if world > 1:
             gather_batch(o, dst=0)          # final waveform gather on rank 0 (RCCL)
+        last.update(o=o, z=z, duration=duration)
         return o
 
     for _ in range(args.warmup):
         step()
-    net._engine.profile(True)
-    net._engine.profile_read(reset=True)
+    eng.profile(False)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -166,8 +250,21 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    launches, conv_ms, conv_flops, conv_bytes = net._engine.profile_read(reset=True)
-    net._engine.profile(False)
+
+    # ---- second, untimed pass: HIP events around every launch of the profiled classes (rank 0's numbers are reported)
+    prof = {}
+    if args.profile_steps > 0:
+        eng.profile(True)
+        for _ in range(args.profile_steps):
+            step()
+        torch.cuda.synchronize()
+        for name, cls in (("generator", _lib.PROF_GENERATOR), ("attention", _lib.PROF_ATTENTION), ("frame", _lib.PROF_FRAME)):
+            n, ms, fl, by, bx = eng.profile_read(reset=True, cls=cls)
+            prof[name] = dict(launches=n // args.profile_steps, ms=ms / args.profile_steps, flops=fl / args.profile_steps,
+                              bytes=by / args.profile_steps, bytes_ext=bx / args.profile_steps)
+        eng.profile(False)
+        if world > 1:
+            dist.barrier()
 
     tt = torch.tensor([dt, float(valid_samples)], dtype=torch.float64, device=dev)
     if world > 1:
@@ -184,64 +281,82 @@ def main():
         value = total_valid * args.steps / dt
         audio_s = total_valid / 44100.0
         gen_mode = os.environ.get("VSP_GENERATOR", "f16s")
-        tfl = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-        gbs = conv_bytes / (conv_ms * 1e-3) / 1e9 if conv_ms > 0 else 0.0
-        if gen_mode == "f32":
-            roof = {"bound": "mfma", "achieved": tfl, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": tfl / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                    "kernel": "conv1d_f32_mfma (generator launches, rank 0)"}
-            dtype = "f32"
-        else:
-            # split-f16: every algorithmic FLOP costs three f16 MFMA FLOPs; the layer-boundary traffic is fp32.
-            # Report the roofline that binds (larger fraction); both are kept for the record.
-            f_hbm, f_mfma = gbs / PEAK_HBM_GBS, 3.0 * tfl / PEAK_F16_MFMA_TFLOPS
-            if f_hbm >= f_mfma:
-                roof = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": f_hbm}
-            else:
-                roof = {"bound": "mfma", "achieved": 3.0 * tfl, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": f_mfma}
-            # measured ceiling of the f16 matrix core on RANDOM operands (profiles/r01_mfma_lds_loop_microbench.txt:
-            # 1.45-1.65 PFLOP/s, switching power lowers the clock; zero / regular data reach 2.0): the nominal peak
-            # stays the denominator of "frac", this is the practical yardstick beside it
-            roof["mfma_frac_of_measured_random_data_ceiling"] = 3.0 * tfl / MEASURED_F16_MFMA_CEILING_TFLOPS
-            roof.update({"traffic": None,
-                         "kernel": "generator convolutions: cl_conv_f16s + cl_respair_f16s (fused ResBlock pairs), rank 0",
-                         "alg_tflops": tfl, "alg_gbs": gbs, "hbm_frac": f_hbm, "mfma_issue_frac": f_mfma,
-                         "note": "fp32 activations in HBM; f16 MFMA on split operands (3 MFMA per product), fp32-accurate; achieved counts the layer-boundary bytes of SURVEY 8d for every conv, also for the fused pairs whose intermediate never reaches HBM (so traffic < algorithmic bytes there)"})
-            dtype = "f32 (split-f16 MFMA, 3-term)"
-            if gen_mode == "f16":      # opt-in reduced precision: NOT the headline configuration
-                dtype = "f16 operands, f32 accumulate (VSP_GENERATOR=f16: reduced precision, fails the fp32 parity gate)"
-                f_mfma = tfl / PEAK_F16_MFMA_TFLOPS
-                roof["mfma_issue_frac"] = f_mfma
-                roof["note"] = "fp32 activations in HBM; plain f16 MFMA operands (1 MFMA per product)"
-        traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(traffic_file):
-            try:
-                tr = json.load(open(traffic_file))
-                if tr.get("generator") == gen_mode and tr.get("utterances") == B:
-                    roof["traffic"] = tr["hbm_bytes_per_launch"]
-                    roof["traffic_source"] = tr.get("source")
-            except Exception:
-                pass
-        roof.update({"launches": launches, "avg_launch_ms": conv_ms / max(launches, 1),
-                     "alg_flops_per_launch": conv_flops / max(launches, 1),
-                     "alg_bytes_per_launch": conv_bytes / max(launches, 1),
-                     "hbm_frac_whole_path": value / world * ALG_BYTES_PER_SAMPLE / (PEAK_HBM_GBS * 1e9)})
         out = {
             "metric": "44.1kHz samples/sec", "value": value, "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "scaling": "strong" if sharded_global else "weak", "vs_baseline": None,
+            "dtype": "f32 (split-f16 MFMA, 3-term)", "data": "synthetic",
             "rtf": (dt / args.steps) / audio_s,
-            "config": {"workload": f"{args.workload}: {B} {WL_TEXT.get(args.workload, 'utterances')} per GPU, 44.1 kHz, hop 512, "
-                                   "phoneme/duration/F0/energy/noise supplied, random-init (synthetic) weights of "
-                                   "configs/config.json",
-                       "utterances_per_gpu": B, "padded_frames": tf_global,
-                       "valid_samples_per_step": int(total_valid), "parallelism": f"shard{world}",
-                       "generator": gen_mode},
-            "roofline": roof,
+            "config": {"workload": f"{args.workload}: {B_all} {WL_TEXT.get(args.workload, 'utterances')}"
+                                   f"{'' if sharded_global else ' per GPU'}, 44.1 kHz, hop 512, "
+                                   f"{ {'all': 'phoneme/duration/F0/energy/noise supplied', 'duration': 'phoneme/duration/noise supplied, F0 and energy PREDICTED', 'none': 'phonemes + noise supplied, duration / F0 / energy PREDICTED'}[args.controls] }"
+                                   ", random-init (synthetic) weights of configs/config.json",
+                       "utterances_per_gpu": B, "global_batch": B_all * (1 if sharded_global else world),
+                       "padded_frames": tf_global, "valid_samples_per_step": int(total_valid),
+                       "parallelism": f"shard{world}", "generator": gen_mode, "controls": args.controls},
         }
+        if gen_mode == "f32":
+            out["dtype"] = "f32"
+        elif gen_mode == "f16":      # opt-in reduced precision: NOT the headline configuration
+            out["dtype"] = "f16 operands, f32 accumulate (VSP_GENERATOR=f16: reduced precision, fails the fp32 parity gate)"
+        if prof:
+            g = prof["generator"]
+            tfl = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0           # algorithmic TFLOP/s
+            gbs = g["bytes"] / (g["ms"] * 1e-3) / 1e9 if g["ms"] > 0 else 0.0            # SURVEY 8d bytes / time
+            mf = {"f32": 1.0, "f16": 1.0}.get(gen_mode, 3.0)                               # MFMA FLOPs issued per algorithmic FLOP
+            peak = PEAK_F32_MFMA_TFLOPS if gen_mode == "f32" else PEAK_F16_MFMA_TFLOPS
+            f_hbm, f_mfma = gbs / PEAK_HBM_GBS, mf * tfl / peak
+            # the bound is the roof the kernels sit closer to, from measured facts: issued matrix FLOP/s against the
+            # dense f16 peak vs layer-boundary bytes against the HBM peak
+            roof = ({"bound": "mfma", "achieved": mf * tfl, "peak": peak, "unit": "TFLOP/s", "frac": f_mfma}
+                    if f_mfma >= f_hbm else
+                    {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": f_hbm})
+            roof.update({
+                "traffic": None,
+                "kernel": "generator convolutions (g16_conv + g16_pair, fused ResBlock pairs on the 64/32-channel stages), rank 0",
+                "launches": g["launches"], "kernel_ms_per_step": g["ms"], "avg_launch_ms": g["ms"] / max(g["launches"], 1),
+                "alg_tflops": tfl, "alg_flops_per_launch": g["flops"] / max(g["launches"], 1),
+                "alg_gbs": gbs, "alg_bytes_per_launch": g["bytes"] / max(g["launches"], 1),
+                "alg_gbs_with_residual_reads": g["bytes_ext"] / (g["ms"] * 1e-3) / 1e9 if g["ms"] > 0 else 0.0,
+                "hbm_frac": f_hbm, "mfma_issue_frac": f_mfma,
+                "mfma_frac_of_measured_random_data_ceiling": mf * tfl / MEASURED_F16_MFMA_CEILING_TFLOPS if gen_mode != "f32" else None,
+                "hbm_frac_whole_path": value / world * ALG_BYTES_PER_SAMPLE / (PEAK_HBM_GBS * 1e9),
+                "note": "achieved / alg_gbs count SURVEY 8d's layer-boundary bytes (input once + output once per convolution; "
+                        "a fused pair = the two convolutions it replaces = 4 passes), measured with HIP events around every "
+                        "launch in a separate untimed pass; fp32 activations in HBM, f16 MFMA on split operands (3 MFMAs per "
+                        "product) in the default mode",
+            })
+            at, fr = prof["attention"], prof["frame"]
+            if at["ms"] > 0:
+                atf = at["flops"] / (at["ms"] * 1e-3) / 1e12
+                roof["attention"] = {"kernel": "attn_relpos (relative-position attention, reference attentions.py:148-179)",
+                                     "launches": at["launches"], "ms_per_step": at["ms"], "alg_tflops": atf,
+                                     "mfma_frac_of_f32_peak": atf / PEAK_F32_MFMA_TFLOPS,
+                                     "flops_model": "4 H T^2 + 4 H T (2 window + 1) per utterance and layer"}
+            if fr["ms"] > 0:
+                roof["frame_rate_convs"] = {"launches": fr["launches"], "ms_per_step": fr["ms"],
+                                            "alg_tflops": fr["flops"] / (fr["ms"] * 1e-3) / 1e12}
+            # measured HBM traffic of the generator launches from an earlier rocprofv3 --pmc pass of THIS build and
+            # workload (profiles/traffic.json: keyed on generator mode, utterances and padded frames)
+            traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(traffic_file) and not any(os.environ.get(k) for k in ("VSP_LIB_PATH", "VSP_GEN16", "VSP_FUSE_PAIRS", "VSP_CHUNK_MB")):
+                try:
+                    tr = json.load(open(traffic_file))
+                    if tr.get("generator") == gen_mode and tr.get("utterances") == B and tr.get("padded_frames", tf_global) == tf_global \
+                            and tr.get("kernels", "g16") == "g16":
+                        roof["traffic"] = tr["hbm_bytes_per_launch"]
+                        roof["traffic_source"] = "previous PMC pass: " + str(tr.get("source"))
+                        roof["hbm_measured_gbs"] = tr["hbm_bytes_per_launch"] * g["launches"] / (g["ms"] * 1e-3) / 1e9
+                except Exception:
+                    pass
+            out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sd, dims, batch, min(args.cpu_sample, B))
+            frames_all = frames_local
+            gpu_out = dict(o=last["o"], z=last["z"], duration=last["duration"] if torch.is_tensor(last["duration"]) else ctl["duration_control"],
+                           frames=frames_all)
+            out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(
+                sd, dims, {k: v[sl] if isinstance(v, np.ndarray) and v.shape[:1] == (B_all,) else v for k, v in batch.items()},
+                min(args.cpu_sample, B), args.controls, tf_global, noise_np[sl] if sharded_global else noise_np, gpu_out)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define VSP_ABI_VERSION 2
+#define VSP_ABI_VERSION 3
 
 enum {
   VSP_OK = 0,
@@ -96,15 +96,32 @@ const char* vsp_last_error(const vsp_ctx* ctx);
  * enc_p.proj.*, frame_prior_net.emb.*, energy_predictor.predictor.proj.*) are accepted and
  * ignored; unknown keys return VSP_ERR_KEY. */
 int vsp_set_weight(vsp_ctx* ctx, const char* key, const float* host_data, const int64_t* shape, int ndim);
+/* The same for a checkpoint held in another type or on the device (ABI 3; SURVEY 8b's contract): dtype is one of
+ * VSP_DTYPE_*, on_device != 0 means `data` is a HIP device pointer (copied to the host first).  Values are
+ * widened to float32 exactly (f16 / bf16) or rounded once (f64). */
+#define VSP_DTYPE_F32 0
+#define VSP_DTYPE_F16 1
+#define VSP_DTYPE_BF16 2
+#define VSP_DTYPE_F64 3
+int vsp_set_weight_typed(vsp_ctx* ctx, const char* key, const void* data, const int64_t* shape, int ndim, int dtype,
+                         int on_device);
+/* Forget every tensor set so far (start of a new load on a context that was loaded before).  Within one load,
+ * setting "<x>.weight" drops an earlier "<x>.weight_g" / "<x>.weight_v" pair and vice versa. */
+int vsp_begin_weights(vsp_ctx* ctx);
 /* Number of infer-path tensors still missing (0 = ready to finalise). */
 int vsp_missing_weights(const vsp_ctx* ctx);
 /* Size of the packed device arena (depends on the config only). */
 int64_t vsp_weight_arena_bytes(const vsp_ctx* ctx);
 /* Fold + pack (MFMA fragment order) + upload.  dev_arena may be NULL (the library allocates). */
 int vsp_finalize_weights(vsp_ctx* ctx, void* dev_arena);
-/* Multi-GPU: a non-root rank adopts an arena that already holds rank 0's packed bytes
- * (received by an RCCL broadcast); no host weights needed. */
+/* Multi-GPU: a non-root rank adopts an arena that receives rank 0's packed bytes by an RCCL broadcast; no host
+ * weights needed.  vsp_adopt_packed_weights only records the pointer (the bytes may still be in flight): the context
+ * is NOT ready until vsp_commit_adopted_weights, called after the broadcast has completed, has read the arena's
+ * header (one small device-to-host copy + stream sync) and checked magic, ABI version, size and configuration hash.
+ * What rank 0 packed travels in that header -- in particular whether the posterior encoder (voice conversion) is
+ * there -- instead of being inferred from the local config. */
 int vsp_adopt_packed_weights(vsp_ctx* ctx, void* dev_arena);
+int vsp_commit_adopted_weights(vsp_ctx* ctx, void* stream);
 /* The arena this context reads its weights from (for the broadcast on rank 0). */
 int vsp_weight_arena(const vsp_ctx* ctx, void** dev_arena, int64_t* bytes);
 
@@ -182,6 +199,16 @@ int vsp_flow_reverse(vsp_ctx* ctx, void* stream, int B, int Tf, const float* z_p
 int64_t vsp_generator_workspace_bytes(const vsp_ctx* ctx, int B, int T);
 int vsp_generator(vsp_ctx* ctx, void* stream, int B, int T, const float* z, const float* g,
                   float* o, void* workspace, int64_t workspace_bytes);
+
+/* Streamed vocoder (BASELINE config 5; the chunked output loop of reference inference_api.py:50-60 applied to the
+ * vocoder itself): the waveform samples of frames [f0, f1) of z [B][inter][T], computed from those frames plus
+ * vsp_generator_halo_frames() frames on each side -- bit-identical to the same samples of one vsp_generator call.
+ * o_chunk [B][1][(f1 - f0) * prod(upsample_rates)] contiguous; workspace >= vsp_generator_stream_workspace_bytes
+ * for the largest f1 - f0 used. */
+int vsp_generator_halo_frames(const vsp_ctx* ctx);
+int64_t vsp_generator_stream_workspace_bytes(const vsp_ctx* ctx, int B, int chunk_frames);
+int vsp_generator_stream_chunk(vsp_ctx* ctx, void* stream, int B, int T, const float* z, const float* g, int f0, int f1,
+                               float* o_chunk, void* workspace, int64_t workspace_bytes);
 
 /* ---- voice conversion: replaces SynthesizerTrn.voice_conversion (reference models.py:724-732) */
 /* Needs cfg.spec_channels > 0 and every enc_q.* tensor set before vsp_finalize_weights

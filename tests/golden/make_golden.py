@@ -164,6 +164,41 @@ def filelist_case(net):
     run_case(net, "c1_filelist", batch)
 
 
+def vallist_case(net):
+    """SURVEY 8f row 2, end to end: the two shortest rows of the reference's filelists/val.list go through the
+    REFERENCE's own front door (text.cleaned_text_to_sequence, data_utils.py:94-102 field parsing, spk2id of
+    configs/config.json) into SynthesizerTrn.infer as one ragged batch.  The fixture keeps the raw rows and the
+    symbol table (data) so that the test can drive vispeech_amd.text over the same lines."""
+    import json
+    lines = [l.rstrip("\n") for l in open(os.path.join(REF, "filelists", "val.list"), encoding="utf-8")]
+    lines.sort(key=lambda l: sum(int(x) for x in l.split("|")[3].split()))
+    lines = lines[:2]
+    spk2id = json.load(open(os.path.join(REF, "configs", "config.json"), encoding="utf-8"))["data"]["spk2id"]
+    rows = [l.split("|") for l in lines]
+    B, tp = len(rows), max(len(r[2].split(" ")) for r in rows)
+    ids = np.zeros((B, tp), np.int64)
+    dur, f0, en = (np.zeros((B, tp), np.float32) for _ in range(3))
+    lens, sid = np.zeros(B, np.int64), np.zeros(B, np.int64)
+    for b, (spk, uid, phones, durs, f0s, ens) in enumerate(rows):
+        seq = cleaned_text_to_sequence(phones.split(" "))
+        n = len(seq)
+        ids[b, :n], lens[b], sid[b] = seq, n, spk2id[spk]
+        dur[b, :n] = [int(x) for x in durs.split(" ")]
+        f0[b, :n] = [float(x) for x in f0s.strip().split(" ")]
+        en[b, :n] = [float(x) for x in ens.strip().split(" ")]
+    tf = int(dur.sum(axis=1).max())
+    noise = np.random.Generator(np.random.PCG64(8642)).standard_normal((B, 192, tf), dtype=np.float32)
+    batch = dict(phonemes=ids, lengths=lens, sid=sid, duration=dur, f0=f0, energy=en, noise=noise)
+    out = run_case(net, "val_filelist", batch)
+    path = os.path.join(HERE, "val_filelist.npz")
+    keep = ("in_phonemes", "in_lengths", "in_sid", "in_noise", "in_noise_scale", "in_duration", "in_f0", "in_energy",
+            "o", "x_mask", "z", "m_p", "logs_p")
+    np.savez_compressed(path, rows=np.array(lines), symbols=np.array(list(ref_symbols)),
+                        spk2id_keys=np.array(list(spk2id.keys())), spk2id_vals=np.array(list(spk2id.values()), dtype=np.int64),
+                        **{k: out[k] for k in keep})
+    print(f"val_filelist: rows {[r[1] for r in rows]} -> {os.path.getsize(path)/1024:.0f} KiB")
+
+
 def vc_case(net, dims):
     """SynthesizerTrn.voice_conversion (reference models.py:724-732) on a ragged batch of synthetic
     linear spectrograms (|N(0,1)| magnitudes, the scale of spectrogram_torch output on speech)."""
@@ -192,7 +227,8 @@ def vc_case(net, dims):
 
 
 def main():
-    """``make_golden.py`` rewrites everything; ``make_golden.py vc`` only voice_conversion.npz."""
+    """``make_golden.py`` rewrites everything; ``make_golden.py vc`` only voice_conversion.npz, ``vallist`` only
+    val_filelist.npz."""
     torch.manual_seed(0)
     torch.set_num_threads(8)
     net, dims = build_reference()
@@ -208,6 +244,8 @@ def main():
         # max_len truncation + [B,1,Tp] duration tensor + pitch predicted only
         run_case(net, "maxlen_dur3d", b3, use_pitch=False, max_len=20, dur_3d=True, noise_scale=1.0)
         filelist_case(net)
+    if not only or "vallist" in only:
+        vallist_case(net)
     if not only or "spline" in only:
         spline_case()
     if not only or "vc" in only:

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), s
     assert sorted(_lib.SIGNATURES) == syms, "ctypes signature table and header disagree"
-    assert lib.vsp_abi_version() == 2
+    assert lib.vsp_abi_version() == _lib.ABI_VERSION == 3
 
 
 @pytest.fixture()
@@ -97,7 +97,7 @@ def test_arena_and_workspace_sizes(ctx):
     n_params = sum(int(np.prod(s)) for k, s in state_dict_schema(ModelDims()).items()
                    if used_by_infer(k) or k.startswith("enc_q."))
     # packed arena holds every infer-path parameter and the posterior encoder (weight_g folded away, some zero padding)
-    assert 0.9 * 4 * n_params < arena < 1.5 * 4 * n_params   # generator weights are held in both packings
+    assert 0.9 * 4 * n_params < arena < 2.0 * 4 * n_params   # generator weights are held in several packings
     e1, e2 = lib.vsp_encode_workspace_bytes(h, 2, 40), lib.vsp_encode_workspace_bytes(h, 4, 40)
     assert 0 < e1 < e2
     d1, d2 = lib.vsp_decode_workspace_bytes(h, 1, 40, 100), lib.vsp_decode_workspace_bytes(h, 1, 40, 200)
@@ -145,3 +145,36 @@ def test_model_refuses_cpu_device():
     args, kwargs = vcfg.synthesizer_args(vcfg.default_hparams())
     with pytest.raises(RuntimeError):
         SynthesizerTrn(*args, device="cpu", **kwargs)
+
+
+def test_typed_weights_and_begin_weights_host_logic(ctx):
+    """ABI 3 host logic (no GPU): vsp_set_weight_typed widens f16 / bf16 / f64 host data, rejects unknown dtypes;
+    vsp_begin_weights forgets a load; a folded '<x>.weight' and a weight_g / weight_v pair replace each other."""
+    import torch
+    lib, h = ctx
+    dims = ModelDims()
+    schema = state_dict_schema(dims)
+    n_used = sum(1 for k in schema if used_by_infer(k))
+    key = "dec.conv_pre.weight"
+    shape = schema[key]
+    arr = (C.c_int64 * len(shape))(*shape)
+    for name, dt in (("float16", torch.float16), ("bfloat16", torch.bfloat16), ("float64", torch.float64)):
+        t = torch.randn(*shape).to(dt).contiguous()
+        rc = lib.vsp_set_weight_typed(h, key.encode(), C.c_void_p(t.data_ptr()), arr, len(shape), _lib.DTYPES[name], 0)
+        assert rc == 0, lib.vsp_last_error(h)
+    assert lib.vsp_missing_weights(h) == n_used - 1
+    t = torch.zeros(*shape)
+    assert lib.vsp_set_weight_typed(h, key.encode(), C.c_void_p(t.data_ptr()), arr, len(shape), 9, 0) == -1
+    # folded vs weight-norm forms of one layer: the later one wins, never both
+    vk, gk = "dec.ups.0.weight_v", "dec.ups.0.weight_g"
+    assert _set(lib, h, vk, np.zeros(schema[vk], np.float32)) == 0 and _set(lib, h, gk, np.zeros(schema[gk], np.float32)) == 0
+    assert lib.vsp_missing_weights(h) == n_used - 3
+    assert _set(lib, h, "dec.ups.0.weight", np.zeros(schema[vk], np.float32)) == 0      # folded form: replaces the pair
+    assert lib.vsp_missing_weights(h) == n_used - 3                                      # (both still satisfied by it)
+    assert _set(lib, h, vk, np.zeros(schema[vk], np.float32)) == 0                      # back: the folded tensor is dropped
+    assert lib.vsp_missing_weights(h) == n_used - 2                                      # ... so weight_g is missing again
+    assert lib.vsp_begin_weights(h) == 0
+    assert lib.vsp_missing_weights(h) == n_used
+    # an adopted arena cannot be committed without a device (and a context is not ready before)
+    assert lib.vsp_commit_adopted_weights(h, None) == -2
+    assert lib.vsp_generator_halo_frames(h) == 14

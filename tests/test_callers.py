@@ -1,0 +1,329 @@
+"""The callers either side of the path: checkpoint loader, phoneme-ID front door,
+service wrapper / streamed output.  CPU tests cover the host logic; `-m gpu` tests drive real files and rows
+through the C-ABI and compare with goldens produced by the real reference."""
+import io
+import os
+import threading
+import wave
+
+import numpy as np
+import pytest
+import torch
+
+WAVE_TOL, STAGE_TOL = 1e-4, 1e-5
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+# ------------------------------------------------------------------------------------------ CPU: host logic
+def test_merge_checkpoint_state_is_tolerant_like_the_reference():
+    """reference utils.py:32-43: missing keys and wrong shapes keep the model's value and are reported."""
+    from vispeech_amd.utils import merge_checkpoint_state
+    schema = {"a.weight": (2, 3), "b.bias": (4,), "c.weight": (1,), "d.gone": (2,)}
+    current = {k: np.full(s, 7.0, np.float32) for k, s in schema.items() if k != "d.gone"}
+    saved = {"a.weight": torch.ones(2, 3), "b.bias": torch.ones(5), "extra.key": torch.ones(1)}
+    new, missing, mismatched = merge_checkpoint_state(saved, schema, current)
+    assert missing == ["c.weight", "d.gone"] and mismatched == ["b.bias"]
+    assert torch.equal(new["a.weight"], torch.ones(2, 3))            # taken from the checkpoint
+    assert (new["b.bias"] == 7.0).all() and (new["c.weight"] == 7.0).all()   # kept
+    assert "d.gone" not in new and "extra.key" not in new            # nothing to keep / not a model key
+
+
+class _FakeNet:
+    """Stands in for SynthesizerTrn in the lock tests: infer blocks until released."""
+    class dims:
+        total_upsample = 4
+        inter_channels = 2
+    device = "cpu"
+
+    def __init__(self):
+        self.started, self.go = threading.Event(), threading.Event()
+
+    def infer(self, ph, ln, **kw):
+        self.started.set()
+        assert self.go.wait(10)
+        B = ph.shape[0]
+        o = torch.linspace(-1, 1, B * 12).reshape(B, 1, 12)
+        x_mask = torch.ones(B, 1, 3, dtype=torch.bool)
+        x_mask[0, 0, 2] = False
+        return (o, x_mask, None, None, None, None)
+
+
+def test_service_is_single_flight_and_never_queues():
+    """reference inference_api.py:13, 37: mutex.acquire(blocking=False) -- a second request is refused at once."""
+    from vispeech_amd.service import Busy, SynthesisService, pcm16
+    net = _FakeNet()
+    svc = SynthesisService(net)
+    batch = dict(phonemes=np.zeros((2, 3), np.int64), lengths=np.array([3, 3]), sid=np.array([0, 1]))
+    res = {}
+    th = threading.Thread(target=lambda: res.update(first=svc.synthesize(batch)))
+    th.start()
+    assert net.started.wait(10) and svc.busy
+    assert svc.synthesize(batch) is None                 # refused, not queued
+    assert svc.wav_bytes(batch) is None
+    with pytest.raises(Busy):
+        svc.stream(batch)
+    net.go.set()
+    th.join(10)
+    assert not svc.busy
+    first = res["first"]
+    assert first.dtype == np.dtype("<i2") and first.size == 2 * 4          # valid frames only (mask), hop 4
+    np.testing.assert_array_equal(first, pcm16(torch.linspace(-1, 1, 24)[:8]))
+    wav = svc.wav_bytes(batch, utterance=1)              # the lock was released: served again
+    with wave.open(io.BytesIO(wav), "rb") as w:
+        assert (w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()) == (1, 2, 44100, 12)
+
+
+# ------------------------------------------------------------------------------------------ GPU
+gpu = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dims():
+    from vispeech_amd.schema import ModelDims
+    return ModelDims()
+
+
+@pytest.fixture(scope="module")
+def full_weights(dims):
+    from vispeech_amd.synth import synth_state_dict
+    return synth_state_dict(dims, seed=1234)          # the full 753-tensor schema, as a reference checkpoint holds
+
+
+def make_net():
+    from vispeech_amd import config as vcfg
+    from vispeech_amd.models import SynthesizerTrn
+    args, kwargs = vcfg.synthesizer_args(vcfg.default_hparams())
+    return SynthesizerTrn(*args, **kwargs).eval()
+
+
+def golden_infer(net, g):
+    t = lambda a: torch.from_numpy(np.asarray(a)).to(net.device)
+    return net.infer(t(g["in_phonemes"]), t(g["in_lengths"]), sid=t(g["in_sid"]), noise_scale=float(g["in_noise_scale"]),
+                     duration_control=t(g["in_duration"]), pitch_control=t(g["in_f0"]), energy_control=t(g["in_energy"]),
+                     noise=t(g["in_noise"]))
+
+
+@gpu
+def test_checkpoint_file_loads_and_matches_reference_golden(tmp_path, dims, full_weights, golden_dir):
+    """a file in the reference's save format (utils.py:67-70) goes through
+    utils.load_checkpoint into the GPU path and reproduces the reference's outputs; then a second file with a
+    missing key and a wrong-shape key is loaded ON TOP (tolerant branches, utils.py:34-43): nothing changes."""
+    from vispeech_amd.utils import load_checkpoint
+    sd = {k: torch.from_numpy(v) for k, v in full_weights.items()}
+    opt_state = {"state": {0: {"step": torch.tensor(12.0), "exp_avg": torch.zeros(3)}}, "param_groups": [{"lr": 2e-4, "params": [0]}]}
+    p = tmp_path / "G_1000.pth"
+    torch.save({"model": sd, "iteration": 1000, "optimizer": opt_state, "learning_rate": 2e-4}, str(p))
+    net = make_net()
+
+    class Opt:
+        loaded = None
+
+        def load_state_dict(self, s):
+            Opt.loaded = s
+
+    opt = Opt()
+    m, o2, lr, it = load_checkpoint(str(p), net, opt)
+    assert m is net and o2 is opt and lr == 2e-4 and it == 1000 and Opt.loaded["param_groups"][0]["lr"] == 2e-4
+    g = np.load(os.path.join(golden_dir, "ragged_controls.npz"))
+    o, x_mask, (z, z_p, m_p, logs_p), *_ = golden_infer(net, g)
+    assert rel_err(o.cpu().numpy(), g["o"]) <= WAVE_TOL and rel_err(z.cpu().numpy(), g["z"]) <= STAGE_TOL
+    # tolerant reload: one key missing, one with a foreign shape, one changed
+    sd2 = dict(sd)
+    del sd2["dec.conv_post.weight"]
+    sd2["emb_g.weight"] = torch.zeros(3, 5)
+    p2 = tmp_path / "G_2000.pth"
+    torch.save({"model": sd2, "iteration": 2000, "optimizer": opt_state, "learning_rate": 1e-4}, str(p2))
+    _, _, lr2, it2 = load_checkpoint(str(p2), net, None)
+    assert (lr2, it2) == (1e-4, 2000)
+    o2_, *_ = golden_infer(net, g)
+    assert torch.equal(o2_, o)                                       # kept values: bit-identical outputs
+    # a pickle that needs more than the restricted unpickler is refused unless the caller opts in
+    p3 = tmp_path / "G_bad.pth"
+    torch.save({"model": sd, "iteration": 1, "optimizer": opt_state, "learning_rate": 1e-4, "hook": threading.Lock}, str(p3))
+    with pytest.raises(Exception):
+        load_checkpoint(str(p3), net, None)
+
+
+@gpu
+def test_val_filelist_rows_through_the_front_door(dims, full_weights, golden_dir):
+    """rows of the reference's filelists/val.list -> parse_filelist_row -> collate_rows ->
+    infer on the GPU, against the reference's own front door + infer (golden made by make_golden.py vallist)."""
+    from vispeech_amd.text import SymbolTable, collate_rows, parse_filelist_row
+    g = np.load(os.path.join(golden_dir, "val_filelist.npz"))
+    table = SymbolTable([str(s) for s in g["symbols"]])
+    spk2id = {str(k): int(v) for k, v in zip(g["spk2id_keys"], g["spk2id_vals"])}
+    rows = [parse_filelist_row(str(l)) for l in g["rows"]]
+    batch = collate_rows(rows, table, spk2id)
+    for k, gk in (("phonemes", "in_phonemes"), ("lengths", "in_lengths"), ("sid", "in_sid"), ("duration", "in_duration"),
+                  ("f0", "in_f0"), ("energy", "in_energy")):
+        np.testing.assert_array_equal(batch[k], g[gk])               # same ids / controls as the reference's parser
+    net = make_net()
+    net.load_state_dict(full_weights)
+    t = lambda a: torch.from_numpy(np.asarray(a)).to(net.device)
+    o, x_mask, (z, z_p, m_p, logs_p), *_ = net.infer(
+        t(batch["phonemes"]), t(batch["lengths"]), sid=t(batch["sid"]), noise_scale=float(g["in_noise_scale"]),
+        duration_control=t(batch["duration"]), pitch_control=t(batch["f0"]), energy_control=t(batch["energy"]),
+        noise=t(g["in_noise"]))
+    np.testing.assert_array_equal(x_mask.cpu().numpy(), g["x_mask"])
+    for name, val in (("m_p", m_p), ("logs_p", logs_p), ("z", z)):
+        assert rel_err(val.cpu().numpy(), g[name]) <= STAGE_TOL, name
+    assert rel_err(o.cpu().numpy(), g["o"]) <= WAVE_TOL
+
+
+@gpu
+def test_service_streams_the_same_bytes_and_refuses_while_streaming(dims, full_weights, golden_dir):
+    """chunked PCM16 streaming over the halo streamer == the one-shot waveform, byte for byte;
+    the single-flight lock is held while a stream is open."""
+    from vispeech_amd.service import Busy, SynthesisService
+    g = np.load(os.path.join(golden_dir, "val_filelist.npz"))
+    net = make_net()
+    net.load_state_dict(full_weights)
+    svc = SynthesisService(net, chunk_frames=100)
+    batch = dict(phonemes=g["in_phonemes"], lengths=g["in_lengths"], sid=g["in_sid"], duration=g["in_duration"],
+                 f0=g["in_f0"], energy=g["in_energy"])
+    noise = torch.from_numpy(g["in_noise"]).to(net.device)
+    for utt in (0, 1):
+        whole = svc.synthesize(batch, utterance=utt, noise=noise)
+        frames = int(g["in_duration"][utt].sum())
+        assert whole.size == frames * 512
+        it = svc.stream(batch, utterance=utt, noise=noise)
+        first = next(it)
+        assert len(first) == 2 * 100 * 512 and svc.busy
+        assert svc.synthesize(batch) is None                         # refused while the stream is open
+        with pytest.raises(Busy):
+            svc.stream(batch)
+        rest = b"".join(it)
+        assert not svc.busy
+        assert first + rest == whole.tobytes()
+    # the reference's golden waveform, as PCM16, within one LSB
+    from vispeech_amd.service import pcm16
+    ref = pcm16(g["o"][0, 0, : int(g["in_duration"][0].sum()) * 512])
+    assert np.abs(svc.synthesize(batch, 0, noise).astype(np.int32) - ref.astype(np.int32)).max() <= 1
+    # closing a stream early releases the lock
+    it = svc.stream(batch, noise=noise)
+    next(it)
+    it.close()
+    assert not svc.busy
+
+
+@gpu
+def test_stream_chunk_entry_point_is_bit_identical_to_the_full_vocoder(dims, full_weights):
+    """The C-ABI streamed-generator call (vsp_generator_stream_chunk): any chunking == one vsp_generator call."""
+    import ctypes as C
+    net = make_net()
+    net.load_state_dict(full_weights)
+    eng = net._engine
+    rng = np.random.Generator(np.random.PCG64(5))
+    B, T = 2, 333
+    z = torch.from_numpy(rng.standard_normal((B, dims.inter_channels, T), dtype=np.float32)).cuda()
+    gv = torch.from_numpy(full_weights["emb_g.weight"][[3, 40]]).cuda()
+    full = eng.generator(z, gv)
+    halo = eng.generator_halo
+    assert 13 <= halo <= 16
+    lib = eng.lib
+    ws_bytes = lib.vsp_generator_stream_workspace_bytes(eng.ctx, B, 120)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for f0, f1 in ((0, 120), (120, 121), (121, 240), (240, 333), (5, 37)):
+        o = torch.empty(B, 1, (f1 - f0) * 512, device="cuda")
+        rc = lib.vsp_generator_stream_chunk(eng.ctx, stream, B, T, C.c_void_p(z.data_ptr()), C.c_void_p(gv.data_ptr()),
+                                            f0, f1, C.c_void_p(o.data_ptr()), C.c_void_p(ws.data_ptr()), ws_bytes)
+        assert rc == 0, lib.vsp_last_error(eng.ctx)
+        torch.cuda.synchronize()
+        assert torch.equal(o, full[:, :, f0 * 512:f1 * 512]), (f0, f1)
+    # error paths: bad range, short workspace
+    o = torch.empty(B, 1, 512, device="cuda")
+    assert lib.vsp_generator_stream_chunk(eng.ctx, stream, B, T, C.c_void_p(z.data_ptr()), C.c_void_p(gv.data_ptr()),
+                                          10, 10, C.c_void_p(o.data_ptr()), C.c_void_p(ws.data_ptr()), ws_bytes) == -1
+    assert lib.vsp_generator_stream_chunk(eng.ctx, stream, B, T, C.c_void_p(z.data_ptr()), C.c_void_p(gv.data_ptr()),
+                                          0, 120, C.c_void_p(o.data_ptr()), C.c_void_p(ws.data_ptr()), 1024) == -6
+
+
+@gpu
+def test_typed_and_device_weights_equal_the_float32_host_load(dims, full_weights, golden_dir):
+    """vsp_set_weight_typed (dtype + host-or-device pointer): a bf16 / fp16 / fp64 checkpoint, on the
+    host or on the device, gives bit-for-bit what its float32 up-cast gives."""
+    g = np.load(os.path.join(golden_dir, "c1_filelist.npz"))
+    ref_out = {}
+    for name, cast in (("bf16", torch.bfloat16), ("f16", torch.float16)):
+        low = {k: torch.from_numpy(v).to(cast) for k, v in full_weights.items()}
+        up = {k: v.to(torch.float32) for k, v in low.items()}
+        a = make_net(); a.load_state_dict(up)                 # float32 host path
+        b = make_net(); b.load_state_dict(low)                # typed host path
+        c = make_net(); c.load_state_dict({k: v.cuda() for k, v in low.items()})   # typed device path
+        oa, ob, oc = (golden_infer(n, g)[0] for n in (a, b, c))
+        assert torch.equal(oa, ob) and torch.equal(oa, oc), name
+        ref_out[name] = oa
+    d = make_net(); d.load_state_dict({k: torch.from_numpy(v).double() for k, v in full_weights.items()})
+    e = make_net(); e.load_state_dict(full_weights)
+    assert torch.equal(golden_infer(d, g)[0], golden_infer(e, g)[0])
+    assert rel_err(golden_infer(e, g)[0].cpu().numpy(), g["o"]) <= WAVE_TOL
+
+
+@gpu
+def test_second_load_replaces_folded_and_unfolded_forms(dims, full_weights, golden_dir):
+    """a pre-folded '<x>.weight' load followed by a weight_g / weight_v load on the SAME model must use
+    the second checkpoint (and the other way round)."""
+    g = np.load(os.path.join(golden_dir, "c1_filelist.npz"))
+    folded = {}
+    for k, v in full_weights.items():
+        if k.endswith(".weight_g"):
+            continue
+        if k.endswith(".weight_v"):
+            gk = k[:-1] + "g"
+            vv = v.astype(np.float64)
+            nrm = np.sqrt((vv.reshape(vv.shape[0], -1) ** 2).sum(axis=1)).reshape(full_weights[gk].shape)
+            folded[k[:-2]] = (vv * (full_weights[gk] / nrm)).astype(np.float32)
+        else:
+            folded[k] = v
+    other = {k: (v * 0.5 if k.endswith("weight_g") else v) for k, v in full_weights.items()}
+    a = make_net(); a.load_state_dict(folded, strict=False)
+    o_folded = golden_infer(a, g)[0]
+    assert rel_err(o_folded.cpu().numpy(), g["o"]) <= WAVE_TOL
+    a.load_state_dict(other)                                   # same model, now weight_g / weight_v with other values
+    b = make_net(); b.load_state_dict(other)
+    assert torch.equal(golden_infer(a, g)[0], golden_infer(b, g)[0])
+    assert not torch.equal(golden_infer(a, g)[0], o_folded)
+    a.load_state_dict(folded, strict=False)                    # and back
+    assert torch.equal(golden_infer(a, g)[0], o_folded)
+
+
+@gpu
+def test_adopted_arena_needs_a_commit_and_carries_what_rank0_packed(dims, full_weights):
+    """has_voice_conversion of an adopting rank comes from the arena header, and the engine
+    is not ready before the header has been checked."""
+    from vispeech_amd._lib import VspError
+    from vispeech_amd.engine import Engine
+    from vispeech_amd.synth import synth_state_dict
+    infer_only = synth_state_dict(dims, seed=1234, infer_only=True)
+    for sd, want_vc in ((infer_only, False), (full_weights, True)):
+        root = Engine(dims, "cuda:0")
+        root.set_weights(sd)
+        arena = root.finalize()
+        assert root.has_voice_conversion == want_vc
+        peer = Engine(dims, "cuda:0")
+        mine = peer.adopt()
+        mine.zero_()                                             # (fresh memory may hold a stale arena of this process)
+        assert not peer.ready
+        with pytest.raises(VspError):
+            peer.commit_adopted()                                # nothing received yet: no header
+        mine.copy_(arena)                                        # "the broadcast"
+        torch.cuda.synchronize()
+        peer.commit_adopted()
+        assert peer.ready and peer.has_voice_conversion == want_vc
+        z = torch.randn(1, dims.inter_channels, 20, device="cuda")
+        gv = torch.randn(1, dims.gin_channels, device="cuda")
+        assert torch.equal(peer.generator(z, gv), root.generator(z, gv))
+    # a peer built for another configuration refuses the bytes
+    import dataclasses
+    other = Engine(dataclasses.replace(dims, n_speakers=dims.n_speakers + 1), "cuda:0")
+    if other.arena_bytes() == root.arena_bytes():
+        o_arena = other.adopt()
+        o_arena.copy_(arena)
+        with pytest.raises(VspError):
+            other.commit_adopted()

@@ -57,7 +57,12 @@ class _FakeEngine:
 
     def adopt(self):
         self.arena = torch.zeros(self.n, dtype=torch.float32)
+        self.committed = False
         return self.arena
+
+    def commit_adopted(self):          # after the broadcast: the real engine checks the arena header here
+        assert float(self.arena[2]) == 1.0, "commit before the bytes arrived"
+        self.committed = True
 
 
 def _worker(rank, world, port, q):
@@ -75,6 +80,7 @@ def _worker(rank, world, port, q):
         eng = _FakeEngine()
         arena = broadcast_weights(eng, {"w": 1} if rank == 0 else None, src=0)
         assert torch.equal(arena, torch.arange(1000, dtype=torch.float32) * 0.5)
+        assert rank == 0 or eng.committed
         shards = gather_batch(torch.full((2 + (rank == 0), 1, 4), float(rank)), dst=0)
         if rank == 0:
             assert [tuple(s.shape) for s in shards] == [(3, 1, 4), (2, 1, 4)]

@@ -14,6 +14,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VSP_LIB_PATH") or os.path.join(_HERE, "lib", "libvispeech_hip.so")
 
 VSP_MAX_LIST = 8
+ABI_VERSION = 3
+DTYPES = {"float32": 0, "float16": 1, "bfloat16": 2, "float64": 3}   # VSP_DTYPE_*
+PROF_GENERATOR, PROF_ATTENTION, PROF_FRAME = 0, 1, 2
 
 ERRORS = {0: "VSP_OK", -1: "VSP_ERR_ARG", -2: "VSP_ERR_STATE", -3: "VSP_ERR_HIP", -4: "VSP_ERR_KEY",
           -5: "VSP_ERR_SHAPE", -6: "VSP_ERR_WORKSPACE", -7: "VSP_ERR_UNSUPPORTED"}
@@ -48,10 +51,13 @@ SIGNATURES = {
     "vsp_destroy": (_I, [_P]),
     "vsp_last_error": (C.c_char_p, [_P]),
     "vsp_set_weight": (_I, [_P, C.c_char_p, _P, C.POINTER(_I64), _I]),
+    "vsp_set_weight_typed": (_I, [_P, C.c_char_p, _P, C.POINTER(_I64), _I, _I, _I]),
+    "vsp_begin_weights": (_I, [_P]),
     "vsp_missing_weights": (_I, [_P]),
     "vsp_weight_arena_bytes": (_I64, [_P]),
     "vsp_finalize_weights": (_I, [_P, _P]),
     "vsp_adopt_packed_weights": (_I, [_P, _P]),
+    "vsp_commit_adopted_weights": (_I, [_P, _P]),
     "vsp_weight_arena": (_I, [_P, C.POINTER(_P), C.POINTER(_I64)]),
     "vsp_encode_workspace_bytes": (_I64, [_P, _I, _I]),
     "vsp_encode": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _I64]),
@@ -69,6 +75,9 @@ SIGNATURES = {
     "vsp_flow_reverse": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _I64]),
     "vsp_generator_workspace_bytes": (_I64, [_P, _I, _I]),
     "vsp_generator": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _I64]),
+    "vsp_generator_halo_frames": (_I, [_P]),
+    "vsp_generator_stream_workspace_bytes": (_I64, [_P, _I, _I]),
+    "vsp_generator_stream_chunk": (_I, [_P, _P, _I, _I, _P, _P, _I, _I, _P, _P, _I64]),
     "vsp_flow_forward": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _I64]),
     "vsp_voice_conversion_workspace_bytes": (_I64, [_P, _I, _I]),
     "vsp_voice_conversion": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64]),
@@ -81,6 +90,8 @@ SIGNATURES = {
     "vsp_rq_spline": (_I, [_P, _I64, _I, _P, _P, _P, _P, _I, _F, _P, _P]),
     "vsp_profile_enable": (_I, [_P, _I]),
     "vsp_profile_read": (_I, [_P, C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), _I]),
+    "vsp_profile_read_class": (_I, [_P, _I, C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                    C.POINTER(C.c_double), C.POINTER(C.c_double), _I]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -106,7 +117,7 @@ def lib() -> C.CDLL:
             raise ImportError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if l.vsp_abi_version() != 2:
+    if l.vsp_abi_version() != ABI_VERSION:
         raise ImportError("libvispeech_hip ABI version mismatch")
     _lib = l
     return l

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "model.h"
 
@@ -533,17 +534,27 @@ int vsp_destroy(vsp_ctx* ctx) {
 
 const char* vsp_last_error(const vsp_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+int vsp_begin_weights(vsp_ctx* ctx) {
+  if (!ctx) return VSP_ERR_ARG;
+  ctx->raw.clear();
+  ctx->ready = false;
+  ctx->adopted_pending = false;
+  return VSP_OK;
+}
+
 int vsp_set_weight(vsp_ctx* ctx, const char* key, const float* host_data, const int64_t* shape, int ndim) {
   if (!ctx || !key || !host_data || !shape || ndim < 0 || ndim > 8) return ctx ? ctx->fail(VSP_ERR_ARG, "null argument") : VSP_ERR_ARG;
   const std::string k(key);
   // posterior encoder: voice conversion only; ignored by a context built without spec_channels
   if (k.rfind("enc_q.", 0) == 0 && ctx->cfg.spec_channels <= 0) return VSP_OK;
   auto it = ctx->schema.find(k);
+  bool folded_form = false;
   if (it == ctx->schema.end()) {
     // accept a pre-folded "<x>.weight" where the schema has "<x>.weight_v" (remove_weight_norm'ed checkpoint)
     auto iv = ctx->schema.find(k + "_v");
     if (iv == ctx->schema.end()) return ctx->fail(VSP_ERR_KEY, "unknown state_dict key '%s'", key);
     it = iv;
+    folded_form = true;
   }
   const SchemaEntry& e = it->second;
   bool same = (int)e.shape.size() == ndim;
@@ -553,9 +564,72 @@ int vsp_set_weight(vsp_ctx* ctx, const char* key, const float* host_data, const 
   HostTensor t;
   t.shape.assign(shape, shape + ndim);
   t.data.assign(host_data, host_data + t.numel());
+  // one form per layer: a folded "<x>.weight" replaces an earlier weight_g / weight_v pair and vice versa (a second
+  // load on the same context must not keep the other form's tensors)
+  if (folded_form) {
+    ctx->raw.erase(k + "_v");
+    ctx->raw.erase(k + "_g");
+  } else if (k.size() > 9 && (k.compare(k.size() - 9, 9, ".weight_v") == 0 || k.compare(k.size() - 9, 9, ".weight_g") == 0)) {
+    ctx->raw.erase(k.substr(0, k.size() - 2));
+  }
   ctx->raw[k] = std::move(t);
   ctx->ready = false;
   return VSP_OK;
+}
+
+// f16 / bf16 bit patterns -> float (host)
+static float half_bits_to_float(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, exp = (h >> 10) & 0x1fu, man = h & 0x3ffu;
+  uint32_t bits;
+  if (exp == 0) {
+    if (man == 0) bits = sign;
+    else {  // subnormal
+      int e = -1;
+      uint32_t m = man;
+      do { ++e; m <<= 1; } while (!(m & 0x400u));
+      bits = sign | ((uint32_t)(127 - 15 - e) << 23) | ((m & 0x3ffu) << 13);
+    }
+  } else if (exp == 31) bits = sign | 0x7f800000u | (man << 13);
+  else bits = sign | ((exp + 112u) << 23) | (man << 13);
+  float f;
+  std::memcpy(&f, &bits, 4);
+  return f;
+}
+
+int vsp_set_weight_typed(vsp_ctx* ctx, const char* key, const void* data, const int64_t* shape, int ndim, int dtype,
+                         int on_device) {
+  if (!ctx || !key || !data || !shape || ndim < 0 || ndim > 8) return ctx ? ctx->fail(VSP_ERR_ARG, "null argument") : VSP_ERR_ARG;
+  size_t n = 1;
+  for (int i = 0; i < ndim; ++i) {
+    if (shape[i] < 0) return ctx->fail(VSP_ERR_ARG, "negative dimension");
+    n *= (size_t)shape[i];
+  }
+  size_t esz = 0;
+  switch (dtype) {
+    case VSP_DTYPE_F32: esz = 4; break;
+    case VSP_DTYPE_F16: case VSP_DTYPE_BF16: esz = 2; break;
+    case VSP_DTYPE_F64: esz = 8; break;
+    default: return ctx->fail(VSP_ERR_ARG, "vsp_set_weight_typed: unknown dtype %d", dtype);
+  }
+  std::vector<unsigned char> staged;
+  const unsigned char* src = static_cast<const unsigned char*>(data);
+  if (on_device) {
+    staged.resize(n * esz);
+    hipError_t e = hipMemcpy(staged.data(), data, n * esz, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return ctx->fail(VSP_ERR_HIP, "vsp_set_weight_typed(%s): %s", key, hipGetErrorString(e));
+    src = staged.data();
+  }
+  if (dtype == VSP_DTYPE_F32) return vsp_set_weight(ctx, key, reinterpret_cast<const float*>(src), shape, ndim);
+  std::vector<float> f(n);
+  for (size_t i = 0; i < n; ++i) {
+    if (dtype == VSP_DTYPE_F64) { double d; std::memcpy(&d, src + 8 * i, 8); f[i] = (float)d; }
+    else {
+      uint16_t h; std::memcpy(&h, src + 2 * i, 2);
+      if (dtype == VSP_DTYPE_BF16) { const uint32_t b = (uint32_t)h << 16; std::memcpy(&f[i], &b, 4); }
+      else f[i] = half_bits_to_float(h);
+    }
+  }
+  return vsp_set_weight(ctx, key, f.data(), shape, ndim);
 }
 
 int vsp_missing_weights(const vsp_ctx* ctx) {
@@ -594,6 +668,19 @@ static int set_arena(vsp_ctx* ctx, void* dev_arena) {
   return VSP_OK;
 }
 
+static uint32_t config_hash(const vsp_ctx* ctx) {
+  // FNV-1a over the config bytes and the switches that change the packing
+  uint32_t h = 2166136261u;
+  auto mix = [&](const void* p, size_t n) {
+    const unsigned char* b = static_cast<const unsigned char*>(p);
+    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 16777619u; }
+  };
+  mix(&ctx->cfg, sizeof ctx->cfg);
+  const int sw[2] = {ctx->frame_f16s ? 1 : 0, ctx->model.has_cl ? 1 : 0};
+  mix(sw, sizeof sw);
+  return h;
+}
+
 int vsp_finalize_weights(vsp_ctx* ctx, void* dev_arena) {
   if (!ctx) return VSP_ERR_ARG;
   if (ctx->model.total_floats == 0) return ctx->fail(VSP_ERR_STATE, "context was not planned (vsp_create failed)");
@@ -602,10 +689,17 @@ int vsp_finalize_weights(vsp_ctx* ctx, void* dev_arena) {
   std::vector<float> host;
   int rc = fill_model(ctx, host);
   if (rc) return rc;
+  {
+    const uint64_t tf = ctx->model.total_floats;
+    const uint32_t hdr[6] = {ARENA_MAGIC, (uint32_t)VSP_ABI_VERSION, (uint32_t)(tf & 0xffffffffu), (uint32_t)(tf >> 32),
+                             ctx->model.has_vc ? ARENA_FLAG_VC : 0u, config_hash(ctx)};
+    std::memcpy(host.data(), hdr, sizeof hdr);
+  }
   rc = set_arena(ctx, dev_arena);
   if (rc) return rc;
   hipError_t e = hipMemcpy(ctx->arena, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
   if (e != hipSuccess) return ctx->fail(VSP_ERR_HIP, "hipMemcpy(weight arena): %s", hipGetErrorString(e));
+  ctx->adopted_pending = false;
   ctx->ready = true;
   return VSP_OK;
 }
@@ -615,8 +709,28 @@ int vsp_adopt_packed_weights(vsp_ctx* ctx, void* dev_arena) {
   if (ctx->model.total_floats == 0) return ctx->fail(VSP_ERR_STATE, "context was not planned");
   const int rc = set_arena(ctx, dev_arena);
   if (rc) return rc;
-  // the adopted bytes are rank 0's: the posterior encoder is there iff rank 0 loaded enc_q.*
-  ctx->model.has_vc = ctx->cfg.spec_channels > 0;
+  // the bytes may not have arrived yet (the broadcast follows): nothing is known about them until
+  // vsp_commit_adopted_weights has read the header -- fail closed until then
+  ctx->model.has_vc = false;
+  ctx->ready = false;
+  ctx->adopted_pending = true;
+  return VSP_OK;
+}
+
+int vsp_commit_adopted_weights(vsp_ctx* ctx, void* stream) {
+  if (!ctx) return VSP_ERR_ARG;
+  if (!ctx->adopted_pending || !ctx->arena) return ctx->fail(VSP_ERR_STATE, "no adopted arena to commit");
+  uint32_t hdr[6] = {0, 0, 0, 0, 0, 0};
+  hipError_t e = hipMemcpyAsync(hdr, ctx->arena, sizeof hdr, hipMemcpyDeviceToHost, (hipStream_t)stream);
+  if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+  if (e != hipSuccess) return ctx->fail(VSP_ERR_HIP, "arena header read: %s", hipGetErrorString(e));
+  const uint64_t tf = (uint64_t)hdr[2] | ((uint64_t)hdr[3] << 32);
+  if (hdr[0] != ARENA_MAGIC) return ctx->fail(VSP_ERR_STATE, "adopted arena has no header (bytes not broadcast yet, or not a packed arena)");
+  if (hdr[1] != (uint32_t)VSP_ABI_VERSION) return ctx->fail(VSP_ERR_STATE, "adopted arena was packed by ABI %u, this library is ABI %d", hdr[1], VSP_ABI_VERSION);
+  if (tf != ctx->model.total_floats || hdr[5] != config_hash(ctx))
+    return ctx->fail(VSP_ERR_STATE, "adopted arena was packed for a different configuration");
+  ctx->model.has_vc = (hdr[4] & ARENA_FLAG_VC) != 0;
+  ctx->adopted_pending = false;
   ctx->ready = true;
   return VSP_OK;
 }
@@ -1135,6 +1249,66 @@ int vsp_generator(vsp_ctx* ctx, void* stream, int B, int T, const float* z, cons
   run_gen(r, B, T, ext(z, ctx->cfg.inter_channels, T), nullptr, g, o);
   if (ws.overflow) return ctx->fail(VSP_ERR_WORKSPACE, "generator workspace too small (need %zu bytes)", ws.cur);
   return r.rc;
+}
+
+// Receptive field of the generator in input frames (one side), from the configuration: walking back from conv_post,
+// every ResBlock1 stage adds max_k sum_d ((k-1) d / 2 + (k-1) / 2) positions at its rate, every transposed conv maps
+// w positions to ceil((w + (k + s) / 2 - 1) / s), conv_pre adds 3.  (14 for configs/config.json; measured 12.33.)
+int vsp_generator_halo_frames(const vsp_ctx* ctx) {
+  if (!ctx) return VSP_ERR_ARG;
+  const vsp_config& c = ctx->cfg;
+  long w = 3;   // conv_post k7
+  for (int i = c.n_upsamples - 1; i >= 0; --i) {
+    long rb = 0;
+    for (int j = 0; j < c.n_resblock_kernels; ++j) {
+      long acc = 0;
+      const int k = c.resblock_kernel_sizes[j];
+      for (int d = 0; d < c.n_resblock_dilations; ++d) acc += (long)(k - 1) * c.resblock_dilation_sizes[j][d] / 2 + (k - 1) / 2;
+      rb = std::max(rb, acc);
+    }
+    w += rb;
+    const int s = c.upsample_rates[i], k = c.upsample_kernel_sizes[i];
+    w = (w + (k + s) / 2 - 1 + s - 1) / s;
+  }
+  return (int)(w + 3);   // conv_pre k7
+}
+
+int64_t vsp_generator_stream_workspace_bytes(const vsp_ctx* ctx, int B, int chunk_frames) {
+  if (!ctx || B <= 0 || chunk_frames <= 0) return VSP_ERR_ARG;
+  const int span = chunk_frames + 2 * vsp_generator_halo_frames(ctx);
+  const int64_t g = vsp_generator_workspace_bytes(ctx, B, span);
+  if (g < 0) return g;
+  return g + (((int64_t)B * span * total_upsample(ctx->cfg) * (int64_t)sizeof(float) + 255) / 256) * 256;
+}
+
+// Streamed vocoder (BASELINE config 5): the waveform of frames [f0, f1) of z [B][inter][T], computed from those frames
+// plus the halo on both sides (zero padding only at the true ends) -- bit-identical to the same samples of one
+// vsp_generator call over all T frames.  o_chunk [B][1][(f1 - f0) * prod(upsample_rates)], contiguous.
+int vsp_generator_stream_chunk(vsp_ctx* ctx, void* stream, int B, int T, const float* z, const float* g, int f0, int f1,
+                               float* o_chunk, void* workspace, int64_t workspace_bytes) {
+  int rc = check_ready(ctx);
+  if (rc) return rc;
+  if (B <= 0 || T <= 0 || !z || !g || !o_chunk || !workspace || f0 < 0 || f1 <= f0 || f1 > T)
+    return ctx->fail(VSP_ERR_ARG, "vsp_generator_stream_chunk: bad argument");
+  const int halo = vsp_generator_halo_frames(ctx);
+  const int lo = std::max(0, f0 - halo), hi = std::min(T, f1 + halo), span = hi - lo;
+  const long up = total_upsample(ctx->cfg);
+  const int64_t gen_bytes = vsp_generator_workspace_bytes(ctx, B, span);
+  const int64_t scratch = (((int64_t)B * span * up * (int64_t)sizeof(float) + 255) / 256) * 256;
+  if (gen_bytes < 0 || workspace_bytes < gen_bytes + scratch)
+    return ctx->fail(VSP_ERR_WORKSPACE, "stream chunk workspace too small (need %lld bytes)", (long long)(gen_bytes + scratch));
+  float* o_span = static_cast<float*>(workspace);
+  Ws ws(static_cast<char*>(workspace) + scratch, (size_t)(workspace_bytes - scratch), false);
+  Run r{ctx, (hipStream_t)stream, ws};
+  const int inter = ctx->cfg.inter_channels;
+  // the frames [lo, hi) of every channel row: same strides as z, shifted start
+  run_gen(r, B, span, T3{const_cast<float*>(z) + lo, (long)inter * T, (long)T}, nullptr, g, o_span);
+  if (ws.overflow) return ctx->fail(VSP_ERR_WORKSPACE, "stream chunk workspace too small (need %zu bytes)", ws.cur);
+  if (r.rc != VSP_OK) return r.rc;
+  hipError_t e = hipMemcpy2DAsync(o_chunk, (size_t)(f1 - f0) * up * sizeof(float), o_span + (size_t)(f0 - lo) * up,
+                                  (size_t)span * up * sizeof(float), (size_t)(f1 - f0) * up * sizeof(float), (size_t)B,
+                                  hipMemcpyDeviceToDevice, (hipStream_t)stream);
+  return e == hipSuccess ? VSP_OK : ctx->fail(VSP_ERR_HIP, "stream chunk copy: %s", hipGetErrorString(e));
 }
 
 int vsp_rq_spline(void* stream, int64_t n, int nb, const float* x, const float* uw, const float* uh, const float* ud,

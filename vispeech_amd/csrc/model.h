@@ -87,6 +87,14 @@ struct Model {
   bool has_cl = false;  // split-f16 channels-last generator weights present
 };
 
+// The packed arena starts with a header so that a rank that ADOPTS rank 0's bytes (vsp_adopt_packed_weights +
+// vsp_commit_adopted_weights) can check what it received instead of inferring it from its own config:
+//   word 0 magic, 1 ABI version, 2/3 total floats (lo/hi), 4 flags (bit 0: posterior-encoder weights packed),
+//   5 hash of the vsp_config bytes + the packing switches.
+constexpr size_t ARENA_HEADER_FLOATS = 64;
+constexpr uint32_t ARENA_MAGIC = 0x41505356u;   // "VSPA"
+constexpr uint32_t ARENA_FLAG_VC = 1u;
+
 struct SchemaEntry {
   std::vector<int64_t> shape;
   bool used;
@@ -105,6 +113,7 @@ struct vsp_ctx {
   float* arena = nullptr;
   bool arena_owned = false;
   bool ready = false;
+  bool adopted_pending = false;   // an adopted arena whose header has not been checked yet (vsp_commit_adopted_weights)
   int gen_mode = 1;  // 0: f32 MFMA channel-major generator, 1: split-f16 (fp32-accurate) channels-last generator,
                      // 2: same kernels with plain f16 operands (VSP_GENERATOR=f16, opt-in reduced precision)
   bool frame_f16s = true;  // frame/phoneme-rate convs on the split-f16 matrix path (VSP_FRAME=f32: f32 MFMA)

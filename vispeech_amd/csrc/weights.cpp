@@ -225,6 +225,7 @@ int plan_model(vsp_ctx* ctx) {
       c.n_resblock_kernels > VSP_MAX_LIST || c.n_resblock_dilations < 1 || c.n_resblock_dilations > VSP_MAX_LIST)
     return ctx->fail(VSP_ERR_ARG, "list sizes out of range");
   Planner p;
+  p.raw(ARENA_HEADER_FLOATS);  // arena header (model.h): magic, ABI, size, flags, config hash
   p.f16s = ctx->frame_f16s;   // everything up to the generator: encoders, predictors, projection, flows, posterior
   m.emb_sym = p.raw((size_t)c.n_vocab * h);
   m.emb_g = p.raw((size_t)c.n_speakers * gin);

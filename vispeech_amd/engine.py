@@ -52,8 +52,25 @@ class Engine:
 
     # ------------------------------------------------------------------ weights
     def set_weights(self, state_dict: Mapping[str, "np.ndarray | torch.Tensor"], strict: bool = True):
+        """One ``vsp_set_weight[_typed]`` per tensor of a fresh load (``vsp_begin_weights`` first: nothing of an
+        earlier load survives).  float16 / bfloat16 / float64 checkpoints and tensors that already live on the
+        device are handed over as they are (``vsp_set_weight_typed``); everything else is float32 host data."""
         missing, unexpected = [], []
+        _lib.check(self.lib.vsp_begin_weights(self.ctx), self.ctx, "vsp_begin_weights")
+        self.ready = False
         for k, v in state_dict.items():
+            if torch.is_tensor(v) and str(v.dtype).replace("torch.", "") in _lib.DTYPES and (v.is_cuda or v.dtype != torch.float32):
+                t = v.detach().contiguous()
+                shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
+                rc = self.lib.vsp_set_weight_typed(self.ctx, k.encode(), C.c_void_p(t.data_ptr()), shape, t.dim(),
+                                                   _lib.DTYPES[str(t.dtype).replace("torch.", "")], int(t.is_cuda))
+                if t.is_cuda:
+                    torch.cuda.synchronize(t.device)
+                if rc == -4:
+                    unexpected.append(k)
+                    continue
+                _lib.check(rc, self.ctx, f"vsp_set_weight_typed({k})")
+                continue
             a = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
             a = np.ascontiguousarray(a, dtype=np.float32)
             shape = (C.c_int64 * max(a.ndim, 1))(*a.shape)
@@ -87,14 +104,22 @@ class Engine:
         return arena
 
     def adopt(self, arena: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Non-root rank: use an arena whose bytes arrive by broadcast."""
+        """Non-root rank: use an arena whose bytes arrive by broadcast.  The engine is NOT ready until
+        ``commit_adopted()`` has checked the header of the received bytes."""
         if arena is None:
             arena = self._alloc_arena()
         assert arena.numel() * 4 == self.arena_bytes() and arena.is_cuda
         self._arena = arena
         _lib.check(self.lib.vsp_adopt_packed_weights(self.ctx, _ptr(arena)), self.ctx, "vsp_adopt_packed_weights")
-        self.ready = True
+        self.ready = False
         return arena
+
+    def commit_adopted(self) -> None:
+        """After the broadcast: read the arena header (magic, ABI, size, config hash, what rank 0 packed)."""
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.vsp_commit_adopted_weights(self.ctx, self._stream()), self.ctx,
+                       "vsp_commit_adopted_weights")
+        self.ready = True
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):
@@ -161,7 +186,8 @@ class Engine:
             noise = _dev_f32(noise, self.device)
             if tuple(noise.shape) != (B, inter, Tf):
                 raise ValueError(f"noise must be [{B},{inter},{Tf}], got {tuple(noise.shape)}")
-        out = dict(o=self._f(B, 1, Tdec * d.total_upsample),
+        o_buf = self._f(B, 1, max(Tdec * d.total_upsample, 1))      # (never a null pointer: max_len = 0 skips the vocoder)
+        out = dict(o=o_buf[:, :, :Tdec * d.total_upsample] if Tdec * d.total_upsample != o_buf.shape[2] else o_buf,
                    x_mask=torch.empty(B, 1, Tf, dtype=torch.uint8, device=self.device),
                    z=self._f(B, inter, Tf), z_p=self._f(B, inter, Tf), m_p=self._f(B, inter, Tf),
                    logs_p=self._f(B, inter, Tf))
@@ -169,7 +195,7 @@ class Engine:
         with torch.cuda.device(self.device):
             rc = self.lib.vsp_decode(self.ctx, self._stream(), B, Tp, Tf, -1 if max_len is None else int(max_len),
                                      _ptr(enc["x_var"]), _ptr(enc["g"]), _ptr(enc["cum_dur"]),
-                                     _ptr(enc["frame_lengths"]), _ptr(noise), float(noise_scale), _ptr(out["o"]),
+                                     _ptr(enc["frame_lengths"]), _ptr(noise), float(noise_scale), _ptr(o_buf),
                                      _ptr(out["x_mask"]), _ptr(out["z"]), _ptr(out["z_p"]), _ptr(out["m_p"]),
                                      _ptr(out["logs_p"]), _ptr(ws), ws.numel())
         _lib.check(rc, self.ctx, "vsp_decode")
@@ -341,31 +367,40 @@ class Engine:
         _lib.check(rc, self.ctx, "vsp_generator")
         return o
 
-    GENERATOR_HALO = 13   # frames: the generator's receptive field is +-12.33 frames
+    @property
+    def generator_halo(self) -> int:
+        """Frames of context the streamed vocoder adds on each side (``vsp_generator_halo_frames``)."""
+        return int(self.lib.vsp_generator_halo_frames(self.ctx))
 
     def generator_stream(self, z, g, chunk_frames: int = 256):
         """Streamed vocoder (BASELINE config 5): yields the waveform of ``z`` [B][C][T] chunk by chunk
         ([B,1,512*n] tensors) so that the first audio is available after one chunk instead of after
-        the whole utterance.  Each chunk runs the generator on its frames plus a 13-frame halo on
-        both sides (zero padding only at the true ends), so the concatenation is bit-identical to
-        one ``generator(z, g)`` call."""
+        the whole utterance.  Each chunk is one ``vsp_generator_stream_chunk`` call: the generator on its
+        frames plus the halo on both sides (zero padding only at the true ends), so the concatenation is
+        bit-identical to one ``generator(z, g)`` call."""
         z = _dev_f32(z, self.device)
-        T = z.shape[2]
-        up, halo = self.dims.total_upsample, self.GENERATOR_HALO
+        g = _dev_f32(g, self.device).reshape(z.shape[0], -1)
+        B, _, T = z.shape
+        up = self.dims.total_upsample
+        ws = self._workspace("generator_stream", self.lib.vsp_generator_stream_workspace_bytes(self.ctx, B, chunk_frames))
         for f0 in range(0, T, chunk_frames):
             f1 = min(T, f0 + chunk_frames)
-            lo, hi = max(0, f0 - halo), min(T, f1 + halo)
-            o = self.generator(z[:, :, lo:hi].contiguous(), g)
-            yield o[:, :, (f0 - lo) * up:(f1 - lo) * up]
+            o = self._f(B, 1, (f1 - f0) * up)
+            with torch.cuda.device(self.device):
+                rc = self.lib.vsp_generator_stream_chunk(self.ctx, self._stream(), B, T, _ptr(z), _ptr(g), f0, f1,
+                                                         _ptr(o), _ptr(ws), ws.numel())
+            _lib.check(rc, self.ctx, "vsp_generator_stream_chunk")
+            yield o
 
     def profile(self, on: bool) -> None:
         _lib.check(self.lib.vsp_profile_enable(self.ctx, int(on)), self.ctx, "vsp_profile_enable")
 
-    def profile_read(self, reset: bool = True):
-        n, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
-        _lib.check(self.lib.vsp_profile_read(self.ctx, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by), int(reset)),
-                   self.ctx, "vsp_profile_read")
-        return int(n.value), float(ms.value), float(fl.value), float(by.value)
+    def profile_read(self, reset: bool = True, cls: int = _lib.PROF_GENERATOR):
+        """(launches, ms, algorithmic FLOPs, SURVEY-8d bytes, bytes incl. residual / accumulate reads) of one class."""
+        n, ms, fl, by, bx = C.c_int64(), C.c_double(), C.c_double(), C.c_double(), C.c_double()
+        _lib.check(self.lib.vsp_profile_read_class(self.ctx, int(cls), C.byref(n), C.byref(ms), C.byref(fl), C.byref(by),
+                                                   C.byref(bx), int(reset)), self.ctx, "vsp_profile_read_class")
+        return int(n.value), float(ms.value), float(fl.value), float(by.value), float(bx.value)
 
 
 def rq_spline(x, uw, uh, ud, inverse: bool = False, tail_bound: float = 5.0):

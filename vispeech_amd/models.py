@@ -77,12 +77,14 @@ class SynthesizerTrn:
         schema = state_dict_schema(self.dims)
         host = {}
         for k, v in state_dict.items():
-            a = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+            # float32 host copy (what state_dict() / to() hand back); the engine itself receives the tensors as
+            # they are, so a float16 / bfloat16 / float64 or device-resident checkpoint goes through the typed entry
+            a = v.detach().to(torch.float32).cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
             host[k] = np.ascontiguousarray(a, dtype=np.float32)
         missing = [k for k in schema if used_by_infer(k) and k not in host]
         if strict and missing:
             raise RuntimeError(f"load_state_dict: {len(missing)} missing keys, e.g. {missing[:3]}")
-        _, unexpected = self._engine.set_weights(host, strict=strict)
+        _, unexpected = self._engine.set_weights(state_dict, strict=strict)
         self._state = host
         self._engine.finalize()
         return missing, unexpected

@@ -1,0 +1,131 @@
+"""Service wrapper around the synthesis path.
+
+The reference's web app (``inference_api.py:13, 35-65``) guards its one model with a NON-BLOCKING lock: a request
+that arrives while another is being synthesised is answered "busy" at once (``mutex.acquire(blocking=False)``,
+:37), otherwise ``infer`` runs and the waveform is written as a 44.1 kHz PCM16 WAV (:50).  ``SynthesisService``
+keeps those semantics -- one synthesis in flight per model, callers are refused rather than queued -- and adds
+what the MI355X path makes possible: the vocoder output is STREAMED, chunk by chunk, as PCM16 bytes
+(``vsp_generator_stream_chunk``: the 13/14-frame-halo streamer, bit-identical to the one-shot waveform), so the
+first audio leaves after one chunk instead of after the whole utterance.  Pure host logic; all arithmetic runs in
+libvispeech_hip through ``vispeech_amd.models.SynthesizerTrn``.
+"""
+from __future__ import annotations
+
+import io
+import threading
+import wave
+from typing import Dict, Iterator, Optional, Sequence
+
+import numpy as np
+
+
+def pcm16(audio) -> np.ndarray:
+    """float waveform in [-1, 1] -> little-endian int16 (the conversion of ``utils.write_wav``)."""
+    a = audio.detach().cpu().numpy() if hasattr(audio, "detach") else np.asarray(audio)
+    return np.clip(np.rint(np.asarray(a, dtype=np.float32).reshape(-1) * 32767.0), -32768, 32767).astype("<i2")
+
+
+class Busy(RuntimeError):
+    """Another synthesis is in flight (the reference answers such a request with a 'server busy' text)."""
+
+
+class SynthesisService:
+    """One model, one synthesis at a time, never queueing (reference inference_api.py:13, 37)."""
+
+    def __init__(self, net, sampling_rate: int = 44100, chunk_frames: int = 64, noise_scale: float = 0.667):
+        self.net = net
+        self.sampling_rate = int(sampling_rate)
+        self.chunk_frames = int(chunk_frames)
+        self.noise_scale = float(noise_scale)
+        self._lock = threading.Lock()
+
+    # ------------------------------------------------------------------ single-flight
+    def try_acquire(self) -> bool:
+        return self._lock.acquire(blocking=False)
+
+    def release(self) -> None:
+        self._lock.release()
+
+    @property
+    def busy(self) -> bool:
+        return self._lock.locked()
+
+    # ------------------------------------------------------------------ one-shot (what the reference's /tts does)
+    def synthesize(self, batch: Dict[str, "np.ndarray"], utterance: int = 0, noise=None) -> Optional[np.ndarray]:
+        """``batch`` = the arrays of ``vispeech_amd.text.collate_rows`` (phonemes, lengths, sid and optionally
+        duration / f0 / energy).  Returns the PCM16 samples of ``utterance`` (valid part only), or ``None`` if
+        another request is in flight (the reference returns None -> "busy")."""
+        if not self.try_acquire():
+            return None
+        try:
+            o, frames = self._infer(batch, noise)
+            hop = self.net.dims.total_upsample
+            return pcm16(o[utterance, 0, : int(frames[utterance]) * hop])
+        finally:
+            self.release()
+
+    def wav_bytes(self, batch, utterance: int = 0, noise=None) -> Optional[bytes]:
+        """The reference's response body: a mono PCM16 WAV at the model's sampling rate (inference_api.py:50, 64)."""
+        pcm = self.synthesize(batch, utterance, noise)
+        if pcm is None:
+            return None
+        buf = io.BytesIO()
+        with wave.open(buf, "wb") as w:
+            w.setnchannels(1)
+            w.setsampwidth(2)
+            w.setframerate(self.sampling_rate)
+            w.writeframes(pcm.tobytes())
+        return buf.getvalue()
+
+    # ------------------------------------------------------------------ streamed
+    def stream(self, batch, utterance: int = 0, noise=None) -> Iterator[bytes]:
+        """PCM16 bytes of ``utterance``, one vocoder chunk (``chunk_frames`` frames) at a time.  Raises ``Busy``
+        at once when another synthesis is in flight; the lock is held until the generator is exhausted or
+        closed.  The concatenation equals ``synthesize`` byte for byte."""
+        if not self.try_acquire():
+            raise Busy("another synthesis is in flight")
+        return self._stream_locked(batch, utterance, noise)
+
+    def _stream_locked(self, batch, utterance, noise) -> Iterator[bytes]:
+        try:
+            import torch
+            net, eng = self.net, self.net._engine
+            enc, frames, tf = self._encode(batch)
+            z_noise = noise if noise is not None else torch.randn(
+                enc["x_var"].shape[0], net.dims.inter_channels, tf, dtype=torch.float32, device=eng.device)
+            dec = eng.decode(enc, tf, z_noise, self.noise_scale, max_len=0)     # everything but the vocoder
+            hop, left = net.dims.total_upsample, int(frames[utterance]) * net.dims.total_upsample
+            for o in eng.generator_stream(dec["z"], enc["g"], self.chunk_frames):
+                if left <= 0:
+                    break
+                piece = pcm16(o[utterance, 0, : min(left, o.shape[2])])
+                left -= piece.size
+                yield piece.tobytes()
+        finally:
+            self.release()
+
+    # ------------------------------------------------------------------ helpers
+    def _controls(self, batch):
+        return {k: batch.get(k) for k in ("duration", "f0", "energy")}
+
+    def _encode(self, batch):
+        import torch
+        eng = self.net._engine
+        c = self._controls(batch)
+        t = lambda a: None if a is None else torch.as_tensor(np.asarray(a))
+        enc = eng.encode(t(batch["phonemes"]), t(batch["lengths"]), t(batch["sid"]), t(c["duration"]), t(c["f0"]),
+                         t(c["energy"]))
+        frames, tf = eng.frame_lengths_host(enc["frame_lengths"])
+        if tf <= 0:
+            raise ValueError("all durations are zero: nothing to synthesise")
+        return enc, frames, tf
+
+    def _infer(self, batch, noise):
+        import torch
+        net = self.net
+        c = self._controls(batch)
+        t = lambda a: None if a is None else torch.as_tensor(np.asarray(a)).to(net.device)
+        o, x_mask, *_ = net.infer(t(batch["phonemes"]), t(batch["lengths"]), sid=t(batch["sid"]),
+                                  noise_scale=self.noise_scale, duration_control=t(c["duration"]),
+                                  pitch_control=t(c["f0"]), energy_control=t(c["energy"]), noise=noise)
+        return o, x_mask.sum(dim=(1, 2)).cpu().tolist()

@@ -52,6 +52,11 @@ def broadcast_weights(engine, state_dict=None, src: int = 0, group=None) -> torc
         arena = engine.adopt()
     if _world(group) > 1:
         dist.broadcast(arena, src=src, group=group)
+    if rank != src:
+        # the received bytes say what rank 0 packed (posterior encoder or not, configuration hash): check them
+        if arena.is_cuda:
+            torch.cuda.synchronize(arena.device)
+        engine.commit_adopted()
     return arena
 
 
