@@ -182,6 +182,7 @@ void run_encoder(Run& r, const EncoderW& E, int B, int T, T3 x_in, const int64_t
   const int h = c.hidden_channels, f = c.filter_channels;
   T3 X = r.ws.t3(B, h, T), S = r.ws.t3(B, h, T), QKV = r.ws.t3(B, 3 * h, T), AT = r.ws.t3(B, h, T),
      FF = r.ws.t3(B, f, T);
+  void* AP = r.ctx->att_f16s ? r.ws.bytes(3 * attn_pack_bytes(B, c.n_heads, h / c.n_heads, T)) : nullptr;   // packed q | k | v images
   // X = x_in * mask  (1x1 identity is not needed: masked copy through the LN-free path)
   if (!r.dry() && r.ok()) {
     // masked copy: use the conv-free elementwise path
@@ -194,8 +195,12 @@ void run_encoder(Run& r, const EncoderW& E, int B, int T, T3 x_in, const int64_t
     r.conv(a, B);
     if (!r.dry() && r.ok()) {
       const bool prof = r.prof_begin(VSP_PROF_ATTENTION);
-      r.chk(launch_attention(QKV.p, QKV.bs, QKV.cs, r.A(L.ek), r.A(L.ev), lengths, AT.p, AT.bs, AT.cs, B, h,
-                             c.n_heads, T, c.window_size, r.ctx->att_ksplit, r.s), "attention");
+      if (r.ctx->att_f16s)
+        r.chk(launch_attention_f16s(QKV.p, QKV.bs, QKV.cs, r.A(L.ek), r.A(L.ev), lengths, AT.p, AT.bs, AT.cs, B, h,
+                                    c.n_heads, T, c.window_size, AP, r.s), "attention (split f16)");
+      else
+        r.chk(launch_attention(QKV.p, QKV.bs, QKV.cs, r.A(L.ek), r.A(L.ev), lengths, AT.p, AT.bs, AT.cs, B, h,
+                               c.n_heads, T, c.window_size, r.ctx->att_ksplit, r.s), "attention");
       // QK^T and PV: 2 * h * T^2 MAC per utterance; banded relative logits and values: 2 * h * T * (2w+1) MAC
       if (prof) r.prof_end(VSP_PROF_ATTENTION, (double)B * (4.0 * h * (double)T * T + 4.0 * h * (double)T * (2 * c.window_size + 1)),
                            4.0 * B * 4.0 * h * (double)T, 4.0 * B * 4.0 * h * (double)T);
@@ -511,6 +516,7 @@ int vsp_create(const vsp_config* cfg, int device, vsp_ctx** out) {
   ctx->device = device;
   if (const char* e = getenv("VSP_FRAME")) ctx->frame_f16s = strcmp(e, "f32") != 0;
   if (const char* e = getenv("VSP_ATT_KSPLIT")) ctx->att_ksplit = atoi(e);
+  if (const char* e = getenv("VSP_ATT")) ctx->att_f16s = strcmp(e, "f32") != 0;
   build_schema(ctx->cfg, ctx->schema);
   const int rc = plan_model(ctx);
   if (const char* e = getenv("VSP_GENERATOR")) {
@@ -527,6 +533,7 @@ int vsp_create(const vsp_config* cfg, int device, vsp_ctx** out) {
 int vsp_destroy(vsp_ctx* ctx) {
   if (!ctx) return VSP_ERR_ARG;
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
+  if (ctx->att_scratch) (void)hipFree(ctx->att_scratch);
   if (ctx->arena && ctx->arena_owned) (void)hipFree(ctx->arena);
   delete ctx;
   return VSP_OK;
@@ -994,8 +1001,26 @@ int vsp_attention(vsp_ctx* ctx, void* stream, int which, int layer, int B, int T
   const vsp_config& c = ctx->cfg;
   const int h = c.hidden_channels;
   const EncLayer& L = E.layers[layer];
-  hipError_t e = launch_attention(qkv, 3L * h * T, T, ctx->arena + L.ek, ctx->arena + L.ev, lengths, out, (long)h * T, T,
-                                  B, h, c.n_heads, T, c.window_size, ctx->att_ksplit, (hipStream_t)stream);
+  hipError_t e;
+  if (ctx->att_f16s) {
+    // the unit entry has no workspace argument: its packed operand images live in a context-owned scratch buffer
+    // grown on demand (the infer path takes them from the caller's workspace and never allocates)
+    const size_t need = 3 * attn_pack_bytes(B, c.n_heads, h / c.n_heads, T);
+    if (need > ctx->att_scratch_bytes) {
+      (void)hipStreamSynchronize((hipStream_t)stream);
+      if (ctx->att_scratch) (void)hipFree(ctx->att_scratch);
+      ctx->att_scratch = nullptr;
+      ctx->att_scratch_bytes = 0;
+      e = hipMalloc(&ctx->att_scratch, need);
+      if (e != hipSuccess) return ctx->fail(VSP_ERR_HIP, "attention scratch: %s", hipGetErrorString(e));
+      ctx->att_scratch_bytes = need;
+    }
+    e = launch_attention_f16s(qkv, 3L * h * T, T, ctx->arena + L.ek, ctx->arena + L.ev, lengths, out, (long)h * T, T, B, h,
+                              c.n_heads, T, c.window_size, ctx->att_scratch, (hipStream_t)stream);
+  } else {
+    e = launch_attention(qkv, 3L * h * T, T, ctx->arena + L.ek, ctx->arena + L.ev, lengths, out, (long)h * T, T,
+                         B, h, c.n_heads, T, c.window_size, ctx->att_ksplit, (hipStream_t)stream);
+  }
   return e == hipSuccess ? VSP_OK : ctx->fail(VSP_ERR_HIP, "attention: %s", hipGetErrorString(e));
 }
 

@@ -1,0 +1,378 @@
+// Windowed relative-position self-attention (reference attentions.py:148-179 and the pad / reshape helpers
+// :181-243) on the f16 matrix core with SPLIT operands, ONE pass (online softmax).
+//
+//   S_ij = (q_i / sqrt(dk)) . k_j + [|j-i| <= w] (q_i / sqrt(dk)) . Ek[j-i+w]
+//   S_ij = -1e4 where mask_i * mask_j == 0            (attentions.py:166; NOT -inf, gotcha G9)
+//   P = softmax_j S ;  O_i = sum_j P_ij v_j + sum_{|j-i|<=w} P_ij Ev[j-i+w]
+//
+// Round 1 ran this on v_mfma_f32_32x32x2_f32 in two passes (QK^T computed twice, one scalar ds_read_b32 per MFMA
+// operand): 25 TFLOP/s on the 60 s utterance.  Here:
+//   * attn_pack_f16s (once per layer, O(T)): q | k | v fp32 [3H][T] -> f16 hi / lo images in MFMA FRAGMENT ORDER
+//     (q pre-scaled by log2(e) / sqrt(dk) so that the softmax runs on v_exp_f32 = 2^x; power-of-two operand scales keep
+//     the lo parts normal f16 numbers), so the attention blocks move operands by LDS-DMA / 16-byte loads only and
+//     never convert anything;
+//   * attn_relpos_f16s: S^T = K Q^T on v_mfma_f32_16x16x32_f16 (key on the accumulator register, query on the
+//     lane: row statistics are in-register + two cross-lane steps), three MFMAs per product into one fp32
+//     accumulator (hi hi + lo hi + hi lo: fp32-chain accuracy); the probability tile goes from the accumulator
+//     registers straight into the B operand of O^T = V^T P^T (the key permutation this implies is baked into the
+//     packed V image); online softmax: QK^T is computed ONCE; 32-key K / V tiles double-buffered in LDS by
+//     global_load_lds; the (2w+1)-wide band terms use a per-query LDS table of raw scores (relative values are
+//     applied in fp32 at the end, from the final statistics).
+// Mask semantics unchanged: -1e4 (times log2 e in the 2^x domain) for masked pairs, so a fully masked query row
+// gives the uniform average the reference gives; keys beyond T get -inf.
+#include "kernels.h"
+
+#include <cstdlib>
+#include <type_traits>
+#include <utility>
+
+namespace vsp {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int AF_RS = 17;             // row stride of the per-query band tables (2w+1 <= 16)
+constexpr float AF_QS = 128.f;        // operand scales (powers of two): q, k, v, p
+constexpr float AF_KS = 16.f;
+constexpr float AF_VS = 16.f;
+constexpr float AF_PEXP = 14.f;       // p is carried as p * 2^14 (<= 16384: fits f16, its lo part stays normal)
+constexpr float AF_LOG2E = 1.4426950408889634f;
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// x -> hi = f16(x), lo = f16(x - hi), two values at a time.  The empty asm pins the ROUNDED hi that is stored as THE
+// value the residual is taken against: left to itself hipcc re-derived hi for the subtraction by another conversion
+// path that rounds ties differently, which put single elements off by a whole f16 ulp (one q element in ~10^4:
+// found as 3e-5 errors in single query rows of the T = 300 parity case).
+__device__ __forceinline__ void af_split2(f32x2 x, f16x2& h, f16x2& l) {
+  h = __builtin_convertvector(x, f16x2);
+  asm volatile("" : "+v"(h));
+  const f32x2 back = __builtin_convertvector(h, f32x2);
+  l = __builtin_convertvector(x - back, f16x2);
+}
+
+template <class F, int... I>
+__device__ __forceinline__ void af_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void af_for(F&& f) {
+  af_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// bytes of one packed operand image per (utterance, head): Tpad x DK elements, hi + lo halfs
+size_t attn_pack_bytes(int B, int n_heads, int DK, int T) {
+  const size_t tpad = (size_t)(T + 63) / 64 * 64;
+  return (size_t)B * n_heads * tpad * DK * 4;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// qkv [B][3H][T] fp32 -> Qp, Kp: [b][head][tile16][dchunk32][hi|lo][lane][8]  (lane = t % 16 + 16 * ((d % 32) / 8))
+//                        Vp:     [b][head][group32][dtile16][hi|lo][lane][8]  (lane = d % 16 + 16 * q4, element j =
+//                                key 32 g + (j < 4 ? 4 q4 + j : 16 + 4 q4 + j - 4): the order in which a lane of two
+//                                16-key S^T accumulator tiles holds its keys)
+// One block = 64 time steps of one (b, head); values beyond T are zero.
+template <int DK>
+__global__ void __launch_bounds__(256) attn_pack_f16s(const float* __restrict__ qkv, long bs, long cs, int H, int T,
+                                                       _Float16* __restrict__ Qp, _Float16* __restrict__ Kp,
+                                                       _Float16* __restrict__ Vp) {
+  constexpr int NC = DK / 32, ND = DK / 16;
+  __shared__ float tile[DK][65];
+  const int b = blockIdx.z, hd = blockIdx.y, t0 = blockIdx.x * 64, tid = threadIdx.x;
+  const int n_heads = gridDim.y;
+  const size_t tpad = (size_t)gridDim.x * 64;
+  const size_t img = ((size_t)b * n_heads + hd) * tpad * DK * 2;     // halfs per image (hi + lo)
+  const float qscale = AF_QS * AF_LOG2E / sqrtf((float)DK);
+  for (int which = 0; which < 3; ++which) {
+    const float* src = qkv + (size_t)b * bs + (size_t)(which * H + hd * DK) * cs;
+    __syncthreads();
+    for (int idx = tid; idx < DK * 64; idx += 256) {
+      const int d = idx >> 6, tl = idx & 63;
+      tile[d][tl] = t0 + tl < T ? src[(size_t)d * cs + t0 + tl] : 0.f;
+    }
+    __syncthreads();
+    const float sc = which == 0 ? qscale : (which == 1 ? AF_KS : AF_VS);
+    if (which < 2) {
+      _Float16* dst = (which == 0 ? Qp : Kp) + img;
+      for (int u = tid; u < 64 * NC * 4; u += 256) {
+        const int tl = u & 63, c = (u >> 6) % NC, q4 = (u >> 6) / NC;
+        f16x8 vh, vl;
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          f16x2 h2, l2;
+          af_split2(f32x2{tile[c * 32 + q4 * 8 + j][tl] * sc, tile[c * 32 + q4 * 8 + j + 1][tl] * sc}, h2, l2);
+          vh[j] = h2.x; vh[j + 1] = h2.y;
+          vl[j] = l2.x; vl[j + 1] = l2.y;
+        }
+        const size_t blk = ((size_t)((t0 + tl) >> 4) * NC + c) * 2;
+        const int lane = (tl & 15) + 16 * q4;
+        *reinterpret_cast<f16x8*>(dst + (blk * 64 + lane) * 8) = vh;
+        *reinterpret_cast<f16x8*>(dst + ((blk + 1) * 64 + lane) * 8) = vl;
+      }
+    } else {
+      _Float16* dst = Vp + img;
+      for (int u = tid; u < DK * 2 * 4; u += 256) {
+        const int d = u % DK, g = (u / DK) & 1, q4 = u / (2 * DK);
+        f16x8 vh, vl;
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          const int key = g * 32 + (j < 4 ? 4 * q4 + j : 16 + 4 * q4 + (j - 4));     // (key + 1 for element j + 1)
+          f16x2 h2, l2;
+          af_split2(f32x2{tile[d][key] * sc, tile[d][key + 1] * sc}, h2, l2);
+          vh[j] = h2.x; vh[j + 1] = h2.y;
+          vl[j] = l2.x; vl[j + 1] = l2.y;
+        }
+        const size_t blk = ((size_t)((t0 >> 5) + g) * ND + (d >> 4)) * 2;
+        const int lane = (d & 15) + 16 * q4;
+        *reinterpret_cast<f16x8*>(dst + (blk * 64 + lane) * 8) = vh;
+        *reinterpret_cast<f16x8*>(dst + ((blk + 1) * 64 + lane) * 8) = vl;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Block = NWV waves, wave = NQ query tiles of 16.  Keys stream in tiles of 32 through two LDS buffers.
+template <int DK, int NWV, int NQ>
+__global__ void __launch_bounds__(64 * NWV) attn_relpos_f16s(const float* __restrict__ qkv, long bs, long cs,
+                                                            const _Float16* __restrict__ Qp, const _Float16* __restrict__ Kp,
+                                                            const _Float16* __restrict__ Vp, const float* __restrict__ emb_k,
+                                                            const float* __restrict__ emb_v,
+                                                            const int64_t* __restrict__ lengths, float* __restrict__ out,
+                                                            long o_bs, long o_cs, int H, int T, int w) {
+  constexpr int NC = DK / 32, ND = DK / 16;
+  constexpr int QB = 16 * NQ * NWV;                  // queries per block
+  constexpr int KTILE = 2 * NC * 2 * 1024;           // bytes of a 32-key K tile (2 key tiles x NC chunks x hi/lo)
+  constexpr int VTILE = ND * 2 * 1024;               // bytes of a 32-key V tile
+  constexpr int STAGE = KTILE + VTILE;
+  constexpr int NPIECE = STAGE / 1024, NPW = (NPIECE + NWV - 1) / NWV;
+  __shared__ __attribute__((aligned(16))) char kv[2 * STAGE];
+  __shared__ float Rl[QB * AF_RS];                   // relative-key logits (2^x domain)
+  __shared__ float Sb[QB * AF_RS];                   // raw band scores (2^x domain); -inf = no such key
+  __shared__ float Evs[16 * DK];
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, l15 = lane & 15, q4 = lane >> 4;
+  const int b = blockIdx.z, hd = blockIdx.y, i0 = blockIdx.x * QB;
+  const int n_heads = gridDim.y;
+  const int nrel = 2 * w + 1;
+  const int len = lengths ? (int)lengths[b] : T;
+  const size_t tpad = (size_t)(T + 63) / 64 * 64;
+  const size_t img = ((size_t)b * n_heads + hd) * tpad * DK * 2;
+  const uint4* Kg = reinterpret_cast<const uint4*>(Kp + img);
+  const uint4* Vg = reinterpret_cast<const uint4*>(Vp + img);
+  const int ntiles = (T + 31) / 32;
+
+  // ---- K / V tile t -> LDS buffer (t & 1) by LDS-DMA, 1 KiB pieces in fragment order
+  auto stage = [&](int t) {
+    char* dst = kv + (t & 1) * STAGE;
+#pragma unroll
+    for (int u = 0; u < NPW; ++u) {
+      const int p = u * NWV + wave;
+      if (NPIECE % NWV == 0 || p < NPIECE) {
+        const uint4* src = p < KTILE / 1024 ? Kg + ((size_t)t * (KTILE / 1024) + p) * 64 + lane
+                                            : Vg + ((size_t)t * (VTILE / 1024) + (p - KTILE / 1024)) * 64 + lane;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
+      }
+    }
+  };
+  stage(0);
+
+  // ---- Q fragments of this wave's query tiles (B operand), straight from the packed image
+  const int qt0 = (i0 >> 4) + wave * NQ;            // first 16-query tile of this wave
+  f16x8 Qh[NQ][NC], Ql[NQ][NC];
+#pragma unroll
+  for (int n = 0; n < NQ; ++n)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const bool ok = (size_t)(qt0 + n) * 16 < tpad;
+      const _Float16* p = Qp + img + (((size_t)(ok ? qt0 + n : 0) * NC + c) * 2 * 64 + lane) * 8;
+      Qh[n][c] = *reinterpret_cast<const f16x8*>(p);
+      Ql[n][c] = *reinterpret_cast<const f16x8*>(p + 64 * 8);
+    }
+
+  // ---- relative-key logits of the block's queries (fp32, 2^x domain), band-score table, Ev
+  {
+    const float* qrow = qkv + (size_t)b * bs + (size_t)(hd * DK) * cs;
+    const float qs = AF_LOG2E / sqrtf((float)DK);
+    for (int idx = tid; idx < QB * nrel; idx += 64 * NWV) {
+      const int iq = idx % QB, r = idx / QB;
+      float sum = 0.f;
+      if (i0 + iq < T)
+        for (int d = 0; d < DK; ++d) sum += (qrow[(size_t)d * cs + i0 + iq] * qs) * emb_k[r * DK + d];
+      Rl[iq * AF_RS + r] = sum;
+    }
+    for (int idx = tid; idx < QB * AF_RS; idx += 64 * NWV) Sb[idx] = -INFINITY;
+    for (int idx = tid; idx < nrel * DK; idx += 64 * NWV) Evs[idx] = emb_v[idx];
+  }
+
+  f32x4 O[ND][NQ];
+#pragma unroll
+  for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) O[dt][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run[NQ], l_run[NQ];
+#pragma unroll
+  for (int n = 0; n < NQ; ++n) { m_run[n] = -3.0e38f; l_run[n] = 0.f; }
+  const float s_unscale = 1.f / (AF_QS * AF_KS);
+  const float masked = -1e4f * AF_LOG2E;
+
+  for (int t = 0; t < ntiles; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my pieces of tile t have landed
+    __syncthreads();                                      // everybody's have; everybody is done with tile t - 1
+    if (t + 1 < ntiles) stage(t + 1);
+    const char* kb = kv + (t & 1) * STAGE + lane * 16;
+    const char* vb = kb + KTILE;
+    const int j0 = t * 32;
+    // ---- S^T tiles: [key tile kt][query tile n], lane = query l15, register jj = key 16 kt + 4 q4 + jj
+    f32x4 S[2][NQ];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int n = 0; n < NQ; ++n) S[kt][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const f16x8 kh = *reinterpret_cast<const f16x8*>(kb + ((kt * NC + c) * 2) * 1024);
+        const f16x8 kl = *reinterpret_cast<const f16x8*>(kb + ((kt * NC + c) * 2 + 1) * 1024);
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) {
+          S[kt][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, Qh[n][c], S[kt][n], 0, 0, 0);
+          S[kt][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, Qh[n][c], S[kt][n], 0, 0, 0);
+          S[kt][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, Ql[n][c], S[kt][n], 0, 0, 0);
+        }
+      }
+    // ---- scores -> probabilities (online softmax), straight into the B operand of the PV product
+    f16x8 Ph[NQ], Pl[NQ];
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+      const int iq = (wave * NQ + n) * 16 + l15;          // query index inside the block
+      const int i = i0 + iq;
+      const bool near = j0 + 31 >= i0 + (wave * NQ + n) * 16 - w && j0 <= i0 + (wave * NQ + n) * 16 + 15 + w;   // wave-uniform
+      float sv[8];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int j = j0 + 16 * kt + 4 * q4 + jj;
+          float s = S[kt][n][jj] * s_unscale;
+          if (near) {
+            const int rel = j - i + w;
+            if (rel >= 0 && rel < nrel) s += Rl[iq * AF_RS + rel];
+          }
+          if (i >= len || j >= len) s = masked;
+          if (j >= T) s = -INFINITY;
+          if (near) {
+            const int rel = j - i + w;
+            if (rel >= 0 && rel < nrel && j < T) Sb[iq * AF_RS + rel] = s;
+          }
+          sv[4 * kt + jj] = s;
+        }
+      float tmax = sv[0];
+#pragma unroll
+      for (int e = 1; e < 8; ++e) tmax = fmaxf(tmax, sv[e]);
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      const float m_new = fmaxf(m_run[n], tmax);
+      const float alpha = __builtin_amdgcn_exp2f(m_run[n] - m_new);
+      m_run[n] = m_new;
+      float part = 0.f;
+      f16x8 ph, pl;
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        const f32x2 p = {__builtin_amdgcn_exp2f(sv[e] - m_new + AF_PEXP), __builtin_amdgcn_exp2f(sv[e + 1] - m_new + AF_PEXP)};   // p * 2^14
+        part += p.x + p.y;
+        f16x2 h2, l2;
+        af_split2(p, h2, l2);
+        ph[e] = h2.x; ph[e + 1] = h2.y;
+        pl[e] = l2.x; pl[e + 1] = l2.y;
+      }
+      l_run[n] = l_run[n] * alpha + part;
+      Ph[n] = ph;
+      Pl[n] = pl;
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt) O[dt][n] *= alpha;
+    }
+    // ---- O^T += V^T P^T  (contraction over the tile's 32 keys in the packed order)
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt) {
+      const f16x8 vh = *reinterpret_cast<const f16x8*>(vb + (dt * 2) * 1024);
+      const f16x8 vl = *reinterpret_cast<const f16x8*>(vb + (dt * 2 + 1) * 1024);
+#pragma unroll
+      for (int n = 0; n < NQ; ++n) {
+        O[dt][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, Ph[n], O[dt][n], 0, 0, 0);
+        O[dt][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, Ph[n], O[dt][n], 0, 0, 0);
+        O[dt][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, Pl[n], O[dt][n], 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();                                       // band scores of every wave are in Sb
+
+  // ---- normalise, add the relative-value term (fp32, from the final statistics), store
+#pragma unroll
+  for (int n = 0; n < NQ; ++n) {
+    const int iq = (wave * NQ + n) * 16 + l15, i = i0 + iq;
+    float l_tot = l_run[n];
+    l_tot += __shfl_xor(l_tot, 16);
+    l_tot += __shfl_xor(l_tot, 32);                      // sum of p * 2^14 over all keys
+    const float inv_l = 1.f / l_tot;
+    float pb[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      pb[r] = r < nrel ? __builtin_amdgcn_exp2f(Sb[iq * AF_RS + r] - m_run[n] + AF_PEXP) * inv_l : 0.f;
+    if (i < T) {
+      float* orow = out + (size_t)b * o_bs + (size_t)(hd * DK) * o_cs + i;
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int d = 16 * dt + 4 * q4 + jj;
+          float rv = 0.f;
+          for (int e = 0; e < nrel; ++e) rv += pb[e] * Evs[e * DK + d];
+          orow[(size_t)d * o_cs] = O[dt][n][jj] * (inv_l / AF_VS) + rv;
+        }
+    }
+  }
+}
+
+template <int DK, int NWV, int NQ>
+static void launch_attn_f16s(const float* qkv, long qkv_bs, long qkv_cs, const _Float16* Qp, const _Float16* Kp,
+                             const _Float16* Vp, const float* emb_k, const float* emb_v, const int64_t* lengths, float* out,
+                             long o_bs, long o_cs, int B, int H, int n_heads, int T, int window, hipStream_t s) {
+  constexpr int QB = 16 * NQ * NWV;
+  dim3 grid((T + QB - 1) / QB, n_heads, B);
+  hipLaunchKernelGGL((attn_relpos_f16s<DK, NWV, NQ>), grid, dim3(64 * NWV), 0, s, qkv, qkv_bs, qkv_cs, Qp, Kp, Vp, emb_k,
+                     emb_v, lengths, out, o_bs, o_cs, H, T, window);
+}
+
+// workspace: 3 * attn_pack_bytes(B, n_heads, dk, T), 256-byte aligned
+hipError_t launch_attention_f16s(const float* qkv, long qkv_bs, long qkv_cs, const float* emb_k, const float* emb_v,
+                                 const int64_t* lengths, float* out, long o_bs, long o_cs, int B, int H, int n_heads, int T,
+                                 int window, void* workspace, hipStream_t s) {
+  if (n_heads <= 0 || H % n_heads != 0 || 2 * window + 1 > 16 || T <= 0 || !workspace) return hipErrorInvalidValue;
+  const int dk = H / n_heads;
+  const size_t one = attn_pack_bytes(B, n_heads, dk, T);
+  _Float16* Qp = static_cast<_Float16*>(workspace);
+  _Float16* Kp = reinterpret_cast<_Float16*>(static_cast<char*>(workspace) + one);
+  _Float16* Vp = reinterpret_cast<_Float16*>(static_cast<char*>(workspace) + 2 * one);
+  const dim3 pgrid((T + 63) / 64, n_heads, B);
+  // 128-query blocks when they fill the chip; 64-query blocks (one query tile per wave) otherwise
+  const bool small = (long)((T + 127) / 128) * n_heads * B < 512;
+#define VSP_ATTF(DKV)                                                                                                   \
+  hipLaunchKernelGGL((attn_pack_f16s<DKV>), pgrid, dim3(256), 0, s, qkv, qkv_bs, qkv_cs, H, T, Qp, Kp, Vp);             \
+  if (small) launch_attn_f16s<DKV, 4, 1>(qkv, qkv_bs, qkv_cs, Qp, Kp, Vp, emb_k, emb_v, lengths, out, o_bs, o_cs, B, H, n_heads, T, window, s); \
+  else launch_attn_f16s<DKV, 4, 2>(qkv, qkv_bs, qkv_cs, Qp, Kp, Vp, emb_k, emb_v, lengths, out, o_bs, o_cs, B, H, n_heads, T, window, s)
+  if (dk == 96) { VSP_ATTF(96); }
+  else if (dk == 64) { VSP_ATTF(64); }
+  else if (dk == 32) { VSP_ATTF(32); }
+  else return hipErrorInvalidValue;
+#undef VSP_ATTF
+  return hipGetLastError();
+}
+
+}  // namespace vsp

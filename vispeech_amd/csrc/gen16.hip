@@ -135,7 +135,8 @@ __device__ __forceinline__ void g16_split4(const f32x4 v, float slope, bool act,
       asm("v_max_f32 %0, %1, %2" : "=v"(x.x) : "v"(x.x), "v"(y.x));   // leaky-relu = max(x, slope*x), 0 <= slope <= 1
       asm("v_max_f32 %0, %1, %2" : "=v"(x.y) : "v"(x.y), "v"(y.y));
     }
-    const f16x2 xh = __builtin_convertvector(x, f16x2);
+    f16x2 xh = __builtin_convertvector(x, f16x2);
+    asm volatile("" : "+v"(xh));   // the residual is taken against THE rounded value that is stored (attention_f16s.hip: af_split2)
     const f32x2 back = __builtin_convertvector(xh, f32x2);
     const f16x2 xl = __builtin_convertvector((x - back) * 2048.f, f16x2);
     eh[2 * k] = xh.x; eh[2 * k + 1] = xh.y;

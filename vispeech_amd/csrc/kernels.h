@@ -99,6 +99,13 @@ hipError_t launch_attention(const float* qkv, long qkv_bs, long qkv_cs, const fl
                             const float* emb_v, const int64_t* lengths, float* out, long o_bs,
                             long o_cs, int B, int H, int n_heads, int T, int window, int ksplit_mode, hipStream_t s);
 
+// the same on the f16 matrix core with split operands, one pass (attention_f16s.hip); workspace = 3 *
+// attn_pack_bytes(B, n_heads, H / n_heads, T) bytes (the packed q | k | v operand images)
+size_t attn_pack_bytes(int B, int n_heads, int DK, int T);
+hipError_t launch_attention_f16s(const float* qkv, long qkv_bs, long qkv_cs, const float* emb_k, const float* emb_v,
+                                 const int64_t* lengths, float* out, long o_bs, long o_cs, int B, int H, int n_heads, int T,
+                                 int window, void* workspace, hipStream_t s);
+
 // ------------------------------------------------------------------------------------------
 // small kernels (misc.hip)
 // y = LN_channels(x (+ res)) * gamma + beta  (reference modules.py:29-32), eps 1e-5

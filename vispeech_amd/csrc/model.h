@@ -117,6 +117,9 @@ struct vsp_ctx {
   int gen_mode = 1;  // 0: f32 MFMA channel-major generator, 1: split-f16 (fp32-accurate) channels-last generator,
                      // 2: same kernels with plain f16 operands (VSP_GENERATOR=f16, opt-in reduced precision)
   bool frame_f16s = true;  // frame/phoneme-rate convs on the split-f16 matrix path (VSP_FRAME=f32: f32 MFMA)
+  bool att_f16s = true;    // attention on the split-f16 matrix path, one pass (VSP_ATT=f32: the two-pass f32 MFMA kernel)
+  void* att_scratch = nullptr;   // packed operand images for the vsp_attention unit entry (grown on demand; the infer
+  size_t att_scratch_bytes = 0;  // path takes them from the caller's workspace)
   int att_ksplit = -1;     // attention key-split blocks: -1 automatic (under-filled grids), 0 never, 1 always (VSP_ATT_KSPLIT)
   bool gen16 = true;       // generator convs on the 16x16x32 kernels of gen16.hip (VSP_GEN16=0: the round-1 32x32x16 kernels)
   bool fuse_pairs = true;  // ResBlock conv pairs of the 32/64-channel stages as one launch (VSP_FUSE_PAIRS=0: two launches)
