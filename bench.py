@@ -329,10 +329,16 @@ def main():
             at, fr = prof["attention"], prof["frame"]
             if at["ms"] > 0:
                 atf = at["flops"] / (at["ms"] * 1e-3) / 1e12
-                roof["attention"] = {"kernel": "attn_relpos (relative-position attention, reference attentions.py:148-179)",
-                                     "launches": at["launches"], "ms_per_step": at["ms"], "alg_tflops": atf,
-                                     "mfma_frac_of_f32_peak": atf / PEAK_F32_MFMA_TFLOPS,
-                                     "flops_model": "4 H T^2 + 4 H T (2 window + 1) per utterance and layer"}
+                att_f32 = os.environ.get("VSP_ATT") == "f32"
+                roof["attention"] = {
+                    "kernel": ("attn_relpos_f32 (two passes, v_mfma_f32_32x32x2_f32)" if att_f32 else
+                               "attn_pack_f16s + attn_relpos_f16s (one pass, v_mfma_f32_16x16x32_f16 on split operands: 3 MFMAs per product)")
+                              + ", reference attentions.py:148-179",
+                    "launches": at["launches"], "ms_per_step": at["ms"], "alg_tflops": atf,
+                    "mfma_issue_tflops": atf if att_f32 else 3.0 * atf,
+                    "mfma_peak_tflops": PEAK_F32_MFMA_TFLOPS if att_f32 else PEAK_F16_MFMA_TFLOPS,
+                    "mfma_utilisation": atf / PEAK_F32_MFMA_TFLOPS if att_f32 else 3.0 * atf / PEAK_F16_MFMA_TFLOPS,
+                    "flops_model": "4 H T^2 + 4 H T (2 window + 1) per utterance and layer"}
             if fr["ms"] > 0:
                 roof["frame_rate_convs"] = {"launches": fr["launches"], "ms_per_step": fr["ms"],
                                             "alg_tflops": fr["flops"] / (fr["ms"] * 1e-3) / 1e12}

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Copy the judged artifacts of gpurun_out/final/ (tools/final_profile.sh) into profiles/ under a tag.
-usage: tools/refresh_profiles.py r01_final4"""
+usage: tools/refresh_profiles.py r02_final"""
 import glob
 import json
 import os
@@ -11,23 +11,36 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 F = os.path.join(R, "gpurun_out", "final")
 P = os.path.join(R, "profiles")
-for old in glob.glob(os.path.join(P, "r01_final[0-9]_*")):
+for old in glob.glob(os.path.join(P, tag + "_*")):
     os.remove(old)
 shutil.copy(os.path.join(F, "bench.json"), os.path.join(P, f"{tag}_bench.json"))
 shutil.copy(os.path.join(F, "trace", "t_kernel_stats.csv"), os.path.join(P, f"{tag}_kernel_stats.csv"))
+if os.path.exists(os.path.join(F, "trace_c5", "t_kernel_stats.csv")):
+    shutil.copy(os.path.join(F, "trace_c5", "t_kernel_stats.csv"), os.path.join(P, f"{tag}_c5_kernel_stats.csv"))
 shutil.copy(os.path.join(F, "generator_per_launch.txt"), os.path.join(P, f"{tag}_generator_per_launch.txt"))
 shutil.copy(os.path.join(F, "pytest_gpu.txt"), os.path.join(P, f"{tag}_pytest_gpu.txt"))
 shutil.copy(os.path.join(F, "traffic.json"), os.path.join(P, "traffic.json"))
 out = {}
-for f, k in (("bench_c2", "C2"), ("bench_c5", "C5"), ("bench_f16mode", "C3_f16_reduced_precision_mode"),
+for f, k in (("bench_c2", "C2"), ("bench_c5", "C5"), ("bench_controls_duration", "C3_duration_supplied_F0_energy_predicted"),
+             ("bench_controls_none", "C3_all_predictors_on"), ("bench_f16mode", "C3_f16_reduced_precision_mode"),
              ("bench_traced", "C3_under_rocprofv3_trace")):
-    x = json.loads(open(os.path.join(F, f + ".json")).read().strip().splitlines()[-1])
+    path = os.path.join(F, f + ".json")
+    if not os.path.exists(path):
+        continue
+    x = json.loads(open(path).read().strip().splitlines()[-1])
     out[k] = {kk: x[kk] for kk in ("value", "unit", "ms_per_step", "rtf", "dtype")}
     out[k]["workload"] = x["config"]["workload"]
+    out[k]["padded_frames"] = x["config"]["padded_frames"]
+    out[k]["valid_samples_per_step"] = x["config"]["valid_samples_per_step"]
+    if "parity" in x:
+        out[k]["parity"] = x["parity"]
+    if "roofline" in x and "attention" in x["roofline"]:
+        out[k]["attention"] = x["roofline"]["attention"]
+        out[k]["generator_ms_per_step"] = x["roofline"]["kernel_ms_per_step"]
     print(k, round(x["ms_per_step"], 2), "ms", round(x["value"] / 1e6, 1), "M samples/s")
 json.dump(out, open(os.path.join(P, f"{tag}_other_workloads.json"), "w"), indent=1)
 d = json.loads(open(os.path.join(F, "bench.json")).read().strip().splitlines()[-1])
 r = d["roofline"]
 print("C3", round(d["ms_per_step"], 2), "ms", round(d["value"] / 1e6, 1), "M;",
-      {k: r[k] for k in ("bound", "achieved", "frac", "traffic", "alg_bytes_per_launch", "avg_launch_ms", "mfma_issue_frac")},
-      "cpu", round(d["cpu_baseline"]["value"]))
+      {k: r.get(k) for k in ("bound", "achieved", "frac", "traffic", "alg_bytes_per_launch", "avg_launch_ms", "mfma_issue_frac", "hbm_measured_gbs")},
+      "cpu", round(d["cpu_baseline"]["value"]), "parity", d.get("parity"))

@@ -114,9 +114,7 @@ struct Run {
     ClConvArgs a;
     std::memset(&a, 0, sizeof a);
     a.x = x; a.x_bs = x_bs; a.x_ts = L.Cin;
-    const bool g16 = ctx->gen16;
-    a.wh = reinterpret_cast<const uint16_t*>(A(g16 ? L.wg : L.wh));
-    a.wl = reinterpret_cast<const uint16_t*>(A(L.wl));
+    a.wh = reinterpret_cast<const uint16_t*>(A(L.wg));
     a.bias = A((size_t)L.b);
     a.out = out; a.o_bs = o_bs; a.o_ts = L.Cout;
     a.res = res; a.r_bs = r_bs; a.r_ts = L.Cout;
@@ -127,8 +125,7 @@ struct Run {
     a.phases = L.phases; a.ups_p = L.ups_p; a.T_store = T_store;
     a.terms = ctx->gen_mode == 2 ? 1 : 3;
     const bool prof = prof_begin(VSP_PROF_GENERATOR);
-    if (g16) chk(launch_g16_conv(a, B, s), "g16_conv");
-    else chk(launch_cl_conv(a, B, s), "cl_conv_f16s");
+    chk(launch_g16_conv(a, B, s), "g16_conv");
     if (prof) {
       // input once + output once; the residual / accumulate reads go to bytes_ext
       const double in_el = (double)T_in * L.Cin, out_el = (double)T_store * L.Cout;
@@ -136,24 +133,22 @@ struct Run {
                4.0 * B * (in_el + out_el * (1.0 + (res ? 1.0 : 0.0) + (acc_prev ? 1.0 : 0.0))));
     }
   }
-  // fused ResBlock1 pair (respair_f16s.hip): out = x + conv2(lrelu(conv1(lrelu(x)))) [+ out] [/ div]
+  // fused ResBlock1 pair (g16_pair, gen16.hip): out = x + conv2(lrelu(conv1(lrelu(x)))) [+ out] [/ div]
   void clpair(const ClConv& L1, const ClConv& L2, const float* x, float* out, long bs, int T, bool acc_prev, float div,
               int B) {
     if (dry() || !ok()) return;
     ClPairArgs a;
     std::memset(&a, 0, sizeof a);
     a.x = x; a.x_bs = bs; a.out = out; a.o_bs = bs;
-    const bool g16 = ctx->gen16;
-    a.w1h = reinterpret_cast<const uint16_t*>(A(g16 ? L1.wg : L1.wh)); a.w1l = reinterpret_cast<const uint16_t*>(A(L1.wl));
-    a.w2h = reinterpret_cast<const uint16_t*>(A(g16 ? L2.wg : L2.wh)); a.w2l = reinterpret_cast<const uint16_t*>(A(L2.wl));
+    a.w1h = reinterpret_cast<const uint16_t*>(A(L1.wg));
+    a.w2h = reinterpret_cast<const uint16_t*>(A(L2.wg));
     a.b1 = A((size_t)L1.b); a.b2 = A((size_t)L2.b);
     a.C = L1.Cout; a.K = L1.K; a.dil = L1.dil; a.T = T;
     a.slope = 0.1f;                                    // modules.LRELU_SLOPE (reference modules.py:17)
     a.acc_prev = acc_prev ? 1 : 0; a.div = div;
     a.terms = ctx->gen_mode == 2 ? 1 : 3;
     const bool prof = prof_begin(VSP_PROF_GENERATOR);
-    if (g16) chk(launch_g16_pair(a, B, s), "g16_pair");
-    else chk(launch_cl_pair(a, B, s), "cl_respair_f16s");
+    chk(launch_g16_pair(a, B, s), "g16_pair");
     if (prof) {
       // the two convolutions this launch replaces: SURVEY.md 8d charges each its input and its output (4 passes of
       // T x C); with conv2's residual read (and the accumulate read of a ResBlock's last pair): 5 (6) -> bytes_ext
@@ -390,7 +385,7 @@ void run_generator(Run& r, int B, int T, T3 z, const int64_t* in_lengths, const 
           "conv_post");
 }
 
-// Generator.forward on the split-f16 channels-last kernels (conv_f16s.hip): conv_pre stays on the
+// Generator.forward on the split-f16 channels-last kernels (gen16.hip): conv_pre stays on the
 // f32 kernel (input z is channel-major and tiny), its output is transposed once to [B][T][C].
 void run_generator_cl(Run& r, int B, int T, T3 z, const int64_t* in_lengths, const float* g, float* o) {
   const vsp_config& c = r.ctx->cfg;
@@ -456,8 +451,7 @@ void run_generator_cl(Run& r, int B, int T, T3 z, const int64_t* in_lengths, con
         const ResBlockW& rb = m.rbs[i * nk + j];
         const int nd = (int)rb.dil.size();
         bool fuse = r.ctx->fuse_pairs;
-        for (int d = 0; d < nd; ++d)
-          fuse = fuse && (r.ctx->gen16 ? g16_pair_supported(ch, rb.k, rb.dil[d]) : cl_pair_supported(ch, rb.k, rb.dil[d]));
+        for (int d = 0; d < nd; ++d) fuse = fuse && g16_pair_supported(ch, rb.k, rb.dil[d]);
         for (int d = 0; d < nd; ++d) {
           const bool last = d == nd - 1;
           const float div = (last && j == nk - 1) ? (float)nk : 1.f;
@@ -525,7 +519,6 @@ int vsp_create(const vsp_config* cfg, int device, vsp_ctx** out) {
   }
   if (const char* e = getenv("VSP_CHUNK_MB")) ctx->chunk_mb = atof(e);
   if (const char* e = getenv("VSP_FUSE_PAIRS")) ctx->fuse_pairs = atoi(e) != 0;
-  if (const char* e = getenv("VSP_GEN16")) ctx->gen16 = atoi(e) != 0;
   *out = ctx;  // returned even on failure so that vsp_last_error can be read; caller destroys it
   return rc;
 }

@@ -1,0 +1,91 @@
+// Small channels-last kernels of the vocoder: the [B][C][T] -> [B][T][C] transpose of conv_pre's output and conv_post.
+// (The generator's convolutions are in gen16.hip.)
+#include "kernels.h"
+
+namespace vsp {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------
+// [B][C][T] -> [B][T][C] (conv_pre's output enters the channels-last vocoder), 32x32 LDS tiles
+__global__ void __launch_bounds__(256) transpose_ct_kernel(const float* __restrict__ x, long x_bs, long x_cs,
+                                                           float* __restrict__ y, long y_bs, int y_ts, int C, int T) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, c0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + ly + 8 * k, t = t0 + lx;
+    tile[ly + 8 * k][lx] = (c < C && t < T) ? x[(size_t)b * x_bs + (size_t)c * x_cs + t] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int t = t0 + ly + 8 * k, c = c0 + lx;
+    if (t < T && c < C) y[(size_t)b * y_bs + (size_t)t * y_ts + c] = tile[lx][ly + 8 * k];
+  }
+}
+hipError_t launch_transpose_ct(const float* x, long x_bs, long x_cs, float* y, long y_bs, int y_ts, int B, int C,
+                               int T, hipStream_t s) {
+  hipLaunchKernelGGL(transpose_ct_kernel, dim3((T + 31) / 32, (C + 31) / 32, B), dim3(256), 0, s, x, x_bs, x_cs, y,
+                     y_bs, y_ts, C, T);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// conv_post on a channels-last input: o[b][t] = tanh(sum_j sum_c w[c][j] * lrelu(x[b][t+j-pad][c]))
+// (reference models.py:286-288; slope 0.01 = F.leaky_relu's default, gotcha G1).  Block = 256 outputs.
+// The (256+K-1) x C window is one contiguous span of HBM: staged with 16-byte buffer loads (rows
+// outside the utterance read as 0 = the zero padding), activated once, kept in LDS with rows padded
+// to C+4 floats (16-byte aligned, conflict-free ds_read_b128 down a column of rows); the weights are
+// read through the scalar unit (uniform addresses).
+constexpr int CPL_TILE = 256;
+template <int C>
+__global__ void __launch_bounds__(256) conv_post_cl_kernel(const float* __restrict__ x, long x_bs,
+                                                           const float* __restrict__ wt /* [K][C] */, int K,
+                                                           float slope, float* __restrict__ o, long o_bs, int T) {
+  constexpr int RSF = C + 4;
+  constexpr int C4 = C / 4;
+  __shared__ __attribute__((aligned(16))) float xs[(CPL_TILE + 8) * RSF];
+  const int b = blockIdx.y, t0 = blockIdx.x * CPL_TILE, pad = (K - 1) / 2;
+  const int rows = CPL_TILE + K - 1;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x) + (size_t)b * x_bs, 0,
+                                                                      T * C * 4, 0x00020000);
+  const int base = (t0 - pad) * C * 4;
+  for (int idx = threadIdx.x; idx < rows * C4; idx += 256) {
+    const int row = idx / C4, c4 = idx % C4;
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, base + idx * 16, 0, 0);
+    float e[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e[k] = e[k] > 0.f ? e[k] : e[k] * slope;
+    *reinterpret_cast<float4*>(xs + row * RSF + 4 * c4) = make_float4(e[0], e[1], e[2], e[3]);
+  }
+  __syncthreads();
+  const int t = t0 + threadIdx.x;
+  float acc = 0.f;
+  for (int j = 0; j < K; ++j) {
+    const float* xr = xs + (threadIdx.x + j) * RSF;
+    const float* wr = wt + j * C;             // uniform -> scalar loads
+#pragma unroll
+    for (int c4 = 0; c4 < C4; ++c4) {
+      const float4 xv = *reinterpret_cast<const float4*>(xr + 4 * c4);
+      acc += wr[4 * c4 + 0] * xv.x;
+      acc += wr[4 * c4 + 1] * xv.y;
+      acc += wr[4 * c4 + 2] * xv.z;
+      acc += wr[4 * c4 + 3] * xv.w;
+    }
+  }
+  if (t < T) o[(size_t)b * o_bs + t] = tanhf(acc);
+}
+hipError_t launch_conv_post_cl(const float* x, long x_bs, int x_ts, const float* w, int C, int K, float slope,
+                               float* o, long o_bs, int B, int T, hipStream_t s) {
+  if (K > 8 || x_ts != C || (C != 32 && C != 64)) return hipErrorInvalidValue;
+  dim3 grid((T + CPL_TILE - 1) / CPL_TILE, B);
+  if (C == 32)
+    hipLaunchKernelGGL(conv_post_cl_kernel<32>, grid, dim3(256), 0, s, x, x_bs, w, K, slope, o, o_bs, T);
+  else
+    hipLaunchKernelGGL(conv_post_cl_kernel<64>, grid, dim3(256), 0, s, x, x_bs, w, K, slope, o, o_bs, T);
+  return hipGetLastError();
+}
+
+}  // namespace vsp

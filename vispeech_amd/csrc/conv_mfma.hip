@@ -50,7 +50,7 @@ void pack_conv_weights(float* dst, int M, int Cin, int K, const float* dense) {
 
 // Split-f16 variant of the same packing (F16S kernels below): the 4 KiB block of one (m-tile, chunk,
 // tap) holds [k-step 0..1][hi, lo][lane][8 halfs]; lane l = row (l & 31), k = 16*ks + 8*(l >> 5) + j.
-// w = wh + wl * 2^-11 exactly as in conv_f16s.hip.
+// w = wh + wl * 2^-11 exactly as in gen16.hip.
 void pack_conv_weights_f16s(float* dst_f, int M, int Cin, int K, const float* dense) {
   const int nc = (Cin + CONV_CK - 1) / CONV_CK;
   std::memset(dst_f, 0, packed_conv_floats(M, Cin, K) * sizeof(float));
@@ -77,7 +77,7 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // F16S: the same implicit GEMM on v_mfma_f32_32x32x16_f16 with fp32-accurate split operands (three
-// MFMAs per product into an HH and a CROSS accumulator, conv_f16s.hip) -- 16/3 x the f32 matrix rate.
+// MFMAs per product into an HH and a CROSS accumulator, gen16.hip) -- 16/3 x the f32 matrix rate.
 // The staged window is then kept as f16 PAIRS of adjacent input channels, P[ci/2][t] (hi image, lo
 // image; time contiguous, same bytes as the f32 window): a B fragment (8 consecutive ci of one time
 // column) is four conflict-free ds_read_b32, and staging stays a 16-byte ds_write per four columns.

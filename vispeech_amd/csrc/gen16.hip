@@ -1,5 +1,10 @@
-// Vocoder convolutions on v_mfma_f32_16x16x32_f16 with SPLIT operands (fp32-accurate; conv_f16s.hip has the
-// arithmetic: x = xh + xl * 2^-11, three MFMAs per product into two accumulators HH / CROSS).
+// Vocoder convolutions on the f16 matrix core with SPLIT operands -- fp32-accurate at ~4.6x the native f32 MFMA rate
+// (measured on MI355X, profiles/r01_exp_split_f16.log: error of the 3-term split 6e-8 * sum|ab|, no worse than an f32
+// fmaf chain):
+//   x = xh + xl * 2^-11,  xh = f16(x),  xl = f16((x - xh) * 2^11)      (exact residual, scaled so that the
+//   w = wh + wl * 2^-11                                                  low part never underflows)
+//   x*w ~= xh*wh + (xh*wl + xl*wh) * 2^-11        (dropped xl*wl term <= 2^-24 |x w|)
+//   -> two f32 accumulators per output tile: HH and CROSS; result = HH + CROSS * 2^-11.
 //
 // Why a second generation of these kernels (round 2):
 //   * MFMA shape.  Under the chip's power cap the 16x16x32 form sustains 1.15x the FLOP/s of 32x32x16 on
@@ -50,6 +55,22 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // copied from the SAME source bytes (slice 0: L2-hot), bit 6 no vmcnt waits.  0 in the product build.
 #ifndef G16_DIAG
 #define G16_DIAG 0
+#endif
+
+// G16_STAMPS (diagnostic build, tools/stamps_g16.py): waves 0 and NWV/2 of every 97th block of the VSP_STAMP_G16-th
+// g16_conv launch record wall-clock stamps (s_memrealtime, 100 MHz) at their phase boundaries.
+#ifdef G16_STAMPS
+constexpr int G16_NSTAMP = 256, G16_NSAMPLE = 64;
+__device__ unsigned long long g_g16_stamps[G16_NSAMPLE][G16_NSTAMP];
+__device__ unsigned g_g16_stamp_count;
+#define G16_STAMP()                                                                     \
+  do {                                                                                  \
+    if (stamp_slot >= 0 && stamp_n < G16_NSTAMP - 1 && lane == 0)                       \
+      g_g16_stamps[stamp_slot][stamp_n] = __builtin_amdgcn_s_memrealtime();             \
+    ++stamp_n;                                                                          \
+  } while (0)
+#else
+#define G16_STAMP() ((void)0)
 #endif
 
 constexpr int G16_HALO = 64;   // max (K-1)*dil
@@ -182,7 +203,7 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
   const int lane = tid & 63;
   const int wm = wave / WN, wn = wave % WN;
   const int nmt = (a.phases * a.Cout) >> 4, nch = a.Cin >> 5;
-  // XCD-aware block numbering (as in conv_f16s.hip): XCD k gets the k-th contiguous eighth of the
+  // XCD-aware block numbering (workgroup ids go round-robin over the 8 XCDs): XCD k gets the k-th contiguous eighth of the
   // (utterance, time tile, row group) sequence, row group fastest
   const int gy = gridDim.y, gx = gridDim.x;
   const int nwg = gx * gy * gridDim.z, orig = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
@@ -192,6 +213,17 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
   const int t0 = bx * BT;
   const int K = a.K, S = nch * K;
   const int xrows = BT + (K - 1) * a.dil;        // window rows actually needed
+#ifdef G16_STAMPS
+  int stamp_slot = -1, stamp_n = 0;
+  if ((wave == 0 || wave == NWV / 2) && orig % 97 == 5 && (a.terms & 0x100)) {
+    unsigned sl_ = 0;
+    if (lane == 0) sl_ = atomicAdd(&g_g16_stamp_count, 1u);
+    sl_ = __builtin_amdgcn_readfirstlane(sl_);
+    stamp_slot = sl_ < (unsigned)G16_NSAMPLE ? (int)sl_ : -1;
+    if (stamp_slot >= 0 && lane == 0) g_g16_stamps[stamp_slot][G16_NSTAMP - 1] = wave + 1;   // which half
+  }
+  G16_STAMP();                                   // 0: start
+#endif
 
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.x) + (size_t)b * a.x_bs, 0, a.T_in * a.x_ts * 4, 0x00020000);
@@ -273,10 +305,13 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
   if (S > 1) dma_next(1);
   if (S > 2) dma_next(2);
   x_write(0);                       // (the compiler waits for the window loads here)
+  G16_STAMP();                      // 1: first window converted and written
   int xl_a = 0, xl_b = 0;           // window loads issued in the previous / in this MEM phase (still counted by vmcnt)
   if (nch > 1) { x_issue(1); xl_b = 1; }
   g16_vm_wait<NBW, NL>(false, xl_b);   // slices 0 .. 2 have landed
+  G16_STAMP();                      // 2: slices landed
   G16_BARRIER();
+  G16_STAMP();                      // 3: prologue barrier
   // PING-PONG.  Waves w and w + NWV/2 share a SIMD.  Each wave alternates a MEM phase (all fragments of one step
   // into registers, its LDS-DMA pieces, window staging) with an MFMA phase (the step's MW*NW*3 MFMAs back to back),
   // one barrier between phases; the second half of the block runs one phase behind the first (it starts with a
@@ -317,7 +352,9 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
         else if (behind == 1) g16_vm_wait<NBW, NL>(true, xl_a + xl_b);
         else g16_vm_wait<2 * NBW, NL>(true, xl_a + xl_b);
       }
+      G16_STAMP();                                          // 4 + 4 s: MEM work issued, slice wait done
       G16_BARRIER();                                        // (lgkmcnt(0): the fragments are here)
+      G16_STAMP();                                          // 5 + 4 s: barrier
     }
     // ================= MFMA phase of step s =================
     __builtin_amdgcn_sched_barrier(0);
@@ -335,7 +372,9 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
     });
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
+    G16_STAMP();                                            // 6 + 4 s: MFMAs issued
     G16_BARRIER();
+    G16_STAMP();                                            // 7 + 4 s: barrier
     chunk = chunk_n;
     tap = tap_n;
     slot = slot == NS - 1 ? 0 : slot + 1;
@@ -345,6 +384,7 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
 
   // ---- epilogue: lane = 4 consecutive rows (channels) of one time column: 16-byte accesses.  All residual /
   //      accumulate operands of the wave's tiles are requested first (the fragment registers are dead now).
+  G16_STAMP();                                              // epilogue start
   int oo[MW][NW], orr[MW][NW];
 #pragma unroll
   for (int i = 0; i < MW; ++i) {
@@ -391,7 +431,25 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
       if (a.div != 1.f) v /= a.div;
       __builtin_amdgcn_raw_buffer_store_b128(g16_as_u32x4(v), ro, oo[i][j], 0, 0);
     }
+#ifdef G16_STAMPS
+  G16_STAMP();                                              // stores issued
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  G16_STAMP();                                              // stores retired
+#endif
 }
+
+#ifdef G16_STAMPS
+extern "C" int vsp_debug_stamps_g16(unsigned long long* host, int max_samples, int reset) {
+  unsigned n = 0;
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_g16_stamp_count), sizeof n);
+  if ((int)n > max_samples) n = max_samples;
+  if (n > (unsigned)G16_NSAMPLE) n = G16_NSAMPLE;
+  (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_g16_stamps), (size_t)n * G16_NSTAMP * sizeof(unsigned long long));
+  if (reset) { const unsigned z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_g16_stamp_count), &z, sizeof z); }
+  return (int)n;
+}
+#endif
 
 template <int MW, int NW, int WM, int WN, int TERMS>
 static hipError_t launch_g16_tile(const ClConvArgs& a, int B, hipStream_t s) {
@@ -408,6 +466,17 @@ static hipError_t launch_g16_tile(const ClConvArgs& a, int B, hipStream_t s) {
   const int nmt = a.phases * a.Cout / 16;
   if (nmt % MTB || a.Cin % 32) return hipErrorInvalidValue;
   dim3 grid((a.Nq + BT - 1) / BT, nmt / MTB, B);
+#ifdef G16_STAMPS
+  {  // stamps only in the VSP_STAMP_G16-th launch of this tile type (0-based)
+    static int launch_no = 0;
+    static int target = -2;
+    if (target == -2) { const char* e = getenv("VSP_STAMP_G16"); target = e ? atoi(e) : -1; }
+    ClConvArgs as = a;
+    if (launch_no++ == target) as.terms |= 0x100;
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, as);
+    return hipGetLastError();
+  }
+#endif
   hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, a);
   return hipGetLastError();
 }

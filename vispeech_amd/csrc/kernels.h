@@ -46,10 +46,10 @@ void pack_conv_weights(float* dst, int M, int Cin, int K, const float* dense /* 
 void pack_conv_weights_f16s(float* dst, int M, int Cin, int K, const float* dense /* [M][Cin][K] */);
 
 // ------------------------------------------------------------------------------------------
-// channels-last split-f16 vocoder conv (conv_f16s.hip): x [B][T][Cin], out [B][T][Cout]
+// channels-last split-f16 vocoder conv (gen16.hip): x [B][T][Cin], out [B][T][Cout]
 struct ClConvArgs {
   const float* x; long x_bs; int x_ts;
-  const uint16_t* wh; const uint16_t* wl;   // packed f16 hi / lo fragments
+  const uint16_t* wh;                       // packed f16 A-fragment image, hi | lo interleaved (pack_g16_weights)
   const float* bias;                        // [Cout] or null
   float* out; long o_bs; int o_ts;
   const float* res; long r_bs; int r_ts;
@@ -60,14 +60,13 @@ struct ClConvArgs {
   int phases, ups_p, T_store;               // polyphase transposed conv: row n = phases*q + ph - ups_p
   int terms;                                // 3 = fp32-accurate split product (default), 1 = plain f16 operands
 };
-hipError_t launch_cl_conv(const ClConvArgs& a, int B, hipStream_t s);
 
-// Fused ResBlock1 conv pair on channels-last activations (respair_f16s.hip):
+// Fused ResBlock1 conv pair on channels-last activations (gen16.hip):
 //   out = x + conv2(lrelu(conv1(lrelu(x), dil) + b1), 1) + b2  [+ out] [/ div];  x != out.
 struct ClPairArgs {
   const float* x; long x_bs;                // [B][T][C], batch stride in elements
-  const uint16_t *w1h, *w1l; const float* b1;   // conv1 (dilation dil): packed f16 hi / lo fragments, bias
-  const uint16_t *w2h, *w2l; const float* b2;   // conv2 (dilation 1)
+  const uint16_t* w1h; const float* b1;     // conv1 (dilation dil): packed f16 fragment image, bias
+  const uint16_t* w2h; const float* b2;     // conv2 (dilation 1)
   float* out; long o_bs;
   int C, K, dil, T;
   float slope;                              // leaky-relu slope applied to both convs' inputs
@@ -76,12 +75,6 @@ struct ClPairArgs {
   int tiles;                                // set by the launcher: tiles per utterance
   int xrows;                                // set by the launcher: staged window rows
 };
-bool cl_pair_supported(int C, int K, int dil);
-hipError_t launch_cl_pair(const ClPairArgs& a, int B, hipStream_t s);
-size_t packed_cl_halfs(int Cout, int Cin, int K, int phases);
-void pack_cl_weights(uint16_t* hi, uint16_t* lo, int Cout, int Cin, int K, int phases, const float* dense);
-// second generation of the two kernels above on v_mfma_f32_16x16x32_f16 (gen16.hip): same argument structs, the
-// weights in `wh` / `w1h` / `w2h` are the interleaved hi|lo A-fragment image of pack_g16_weights (wl unused)
 hipError_t launch_g16_conv(const ClConvArgs& a, int B, hipStream_t s);
 bool g16_pair_supported(int C, int K, int dil);
 hipError_t launch_g16_pair(const ClPairArgs& a, int B, hipStream_t s);

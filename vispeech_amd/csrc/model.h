@@ -28,11 +28,10 @@ struct Conv {
   bool f16s = false;   // packed for the split-f16 MFMA path of conv_mfma.hip (same bytes as the f32 packing)
 };
 
-// One channels-last split-f16 conv (conv_f16s.hip); wh / wl offsets in floats (2 halfs per float).
+// One channels-last split-f16 conv (gen16.hip); offsets in floats (2 halfs per float).
 struct ClConv {
   int Cout = 0, Cin = 0, K = 1, dil = 1, pad = 0, phases = 1, ups_p = 0;
-  size_t wh = 0, wl = 0;   // 32x32x16 fragment images (conv_f16s.hip / respair_f16s.hip)
-  size_t wg = 0;           // 16x16x32 interleaved hi|lo A-fragment image (gen16.hip)
+  size_t wg = 0;           // 16x16x32 interleaved hi|lo A-fragment image (pack_g16_weights)
   long b = -1;
 };
 
@@ -121,7 +120,6 @@ struct vsp_ctx {
   void* att_scratch = nullptr;   // packed operand images for the vsp_attention unit entry (grown on demand; the infer
   size_t att_scratch_bytes = 0;  // path takes them from the caller's workspace)
   int att_ksplit = -1;     // attention key-split blocks: -1 automatic (under-filled grids), 0 never, 1 always (VSP_ATT_KSPLIT)
-  bool gen16 = true;       // generator convs on the 16x16x32 kernels of gen16.hip (VSP_GEN16=0: the round-1 32x32x16 kernels)
   bool fuse_pairs = true;  // ResBlock conv pairs of the 32/64-channel stages as one launch (VSP_FUSE_PAIRS=0: two launches)
   double chunk_mb = 0.0;   // generator batch chunk in MiB per activation tensor (VSP_CHUNK_MB; 0 = whole batch: measured faster)
   // profiling: HIP event pairs around the launches of a class (VSP_PROF_* in vispeech_hip.h)

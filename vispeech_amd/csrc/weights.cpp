@@ -180,9 +180,6 @@ struct Planner {
   ClConv clconv(int Cout, int Cin, int K, int dil, int pad, int phases, int ups_p) {
     ClConv c;
     c.Cout = Cout; c.Cin = Cin; c.K = K; c.dil = dil; c.pad = pad; c.phases = phases; c.ups_p = ups_p;
-    const size_t halfs = packed_cl_halfs(Cout, Cin, K, phases);
-    c.wh = raw(halfs / 2);
-    c.wl = raw(halfs / 2);
     c.wg = raw(packed_g16_halfs(phases * Cout, Cin, K) / 2);
     c.b = (long)raw((size_t)Cout);
     return c;
@@ -398,8 +395,6 @@ struct Filler {
       for (int co = 0; co < c.Cout; ++co)
         for (int ci = 0; ci < c.Cin; ++ci)
           for (int t = 0; t < c.K; ++t) dense[(((size_t)ph * c.Cout + co) * c.Cin + ci) * c.K + t] = w(ph, co, ci, t);
-    pack_cl_weights(reinterpret_cast<uint16_t*>(arena.data() + c.wh), reinterpret_cast<uint16_t*>(arena.data() + c.wl),
-                    c.Cout, c.Cin, c.K, c.phases, dense.data());
     // [phase][co][ci][tap] is [row = phase * Cout + co][ci][tap]: the stacked-phase form gen16.hip multiplies
     pack_g16_weights(reinterpret_cast<uint16_t*>(arena.data() + c.wg), c.phases * c.Cout, c.Cin, c.K, dense.data());
     for (int co = 0; co < c.Cout; ++co) arena[c.b + co] = b(co);
