@@ -393,11 +393,17 @@ def test_reduced_precision_mode_is_opt_in_and_gated(dims, weights, golden_dir, m
     assert e > 1e-5          # i.e. really the reduced-precision path
 
 
-def test_fused_resblock_pairs_are_bit_identical_to_two_launches(net, dims, weights, monkeypatch):
-    """The 32/64-channel ResBlock conv pairs run as ONE launch (respair_f16s.hip: the intermediate stays in
-    LDS) by default; VSP_FUSE_PAIRS=0 runs them as two cl_conv_f16s launches.  Same split products, same
-    accumulation order => identical bits, for tiles that start/end anywhere in the utterance."""
-    monkeypatch.setenv("VSP_FUSE_PAIRS", "0")
+@pytest.mark.parametrize("env", [{"VSP_FUSE_PAIRS": "0"}, {"VSP_CHAIN": "0"}, {"VSP_CHAIN": "7", "VSP_CHAIN_CH": "64"},
+                                 {"VSP_CHAIN_WAVES": "4"}, {"VSP_CHAIN_WAVES": "8"}],
+                         ids=["two_launches", "pair_launches", "chains_64ch_too", "chains_256col", "chains_512col"])
+def test_fused_resblock_paths_are_bit_identical(net, dims, weights, monkeypatch, env):
+    """The ResBlocks of the 32/64-channel stages run fused (gen16.hip): by default a whole ResBlock of the
+    32-channel stage is ONE launch (g16_chain: the running x in registers, every intermediate in LDS, the chain's halo
+    recomputed per tile) and a conv pair of the 64-channel stage is one launch (g16_pair).  VSP_CHAIN=0 runs pairs
+    everywhere, VSP_FUSE_PAIRS=0 one g16_conv launch per convolution, VSP_CHAIN_CH=64 chains on both stages.  Same
+    split products, same accumulation order => identical bits, for tiles that start/end anywhere in the utterance."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     from vispeech_amd import config as vcfg
     from vispeech_amd.models import SynthesizerTrn
     args, kwargs = vcfg.synthesizer_args(vcfg.default_hparams())

@@ -96,6 +96,32 @@ struct Run {
     ctx->prof_bytes[cls] += bytes;
     ctx->prof_bytes_ext[cls] += bytes_ext;
   }
+  // fused ResBlock1 chain (g16_chain, gen16.hip): all dilation pairs of one ResBlock in one launch
+  void clchain(const ResBlockW& rb, int ch, const float* x, float* out, long bs, int T, bool acc_prev, float div, int B) {
+    if (dry() || !ok()) return;
+    ClChainArgs a;
+    std::memset(&a, 0, sizeof a);
+    const int np = (int)rb.dil.size();
+    a.x = x; a.x_bs = bs; a.out = out; a.o_bs = bs;
+    for (int p = 0; p < np; ++p) {
+      a.w[2 * p] = reinterpret_cast<const uint16_t*>(A(rb.h1[p].wg));
+      a.w[2 * p + 1] = reinterpret_cast<const uint16_t*>(A(rb.h2[p].wg));
+      a.b[2 * p] = A((size_t)rb.h1[p].b); a.b[2 * p + 1] = A((size_t)rb.h2[p].b);
+      a.dil[p] = rb.dil[p];
+    }
+    a.np = np; a.C = ch; a.K = rb.k; a.T = T;
+    a.slope = 0.1f;                                    // modules.LRELU_SLOPE (reference modules.py:17)
+    a.acc_prev = acc_prev ? 1 : 0; a.div = div;
+    a.terms = ctx->gen_mode == 2 ? 1 : 3;
+    const bool prof = prof_begin(VSP_PROF_GENERATOR);
+    chk(launch_g16_chain(a, B, s), "g16_chain");
+    if (prof) {
+      // the 2 np convolutions this launch replaces, each charged its input and its output
+      const double el = (double)T * ch;
+      prof_end(VSP_PROF_GENERATOR, np * 2.0 * 2.0 * ch * ch * rb.k * (double)T * B, 4.0 * B * el * 4.0 * np,
+               4.0 * B * el * (5.0 * np + (acc_prev ? 1.0 : 0.0)));
+    }
+  }
   void conv(const ConvArgs& a, int B, bool generator = false) {
     if (dry() || !ok()) return;
     const int cls = generator ? VSP_PROF_GENERATOR : VSP_PROF_FRAME;
@@ -148,6 +174,15 @@ struct Run {
     a.acc_prev = acc_prev ? 1 : 0; a.div = div;
     a.terms = ctx->gen_mode == 2 ? 1 : 3;
     const bool prof = prof_begin(VSP_PROF_GENERATOR);
+    if (ctx->pair_via_chain) {                         // experiment: the pair as a one-pair chain (g16_chain's pipelined main loop)
+      ClChainArgs c;
+      std::memset(&c, 0, sizeof c);
+      c.x = x; c.x_bs = bs; c.out = out; c.o_bs = bs;
+      c.w[0] = a.w1h; c.w[1] = a.w2h; c.b[0] = a.b1; c.b[1] = a.b2;
+      c.dil[0] = a.dil; c.np = 1; c.C = a.C; c.K = a.K; c.T = T; c.slope = a.slope;
+      c.acc_prev = a.acc_prev; c.div = a.div; c.terms = a.terms;
+      chk(launch_g16_chain(c, B, s), "g16_chain");
+    } else
     chk(launch_g16_pair(a, B, s), "g16_pair");
     if (prof) {
       // the two convolutions this launch replaces: SURVEY.md 8d charges each its input and its output (4 passes of
@@ -452,6 +487,12 @@ void run_generator_cl(Run& r, int B, int T, T3 z, const int64_t* in_lengths, con
         const int nd = (int)rb.dil.size();
         bool fuse = r.ctx->fuse_pairs;
         for (int d = 0; d < nd; ++d) fuse = fuse && g16_pair_supported(ch, rb.k, rb.dil[d]);
+        const int kbit = rb.k <= 3 ? 1 : rb.k <= 7 ? 2 : 4;
+        if (fuse && (r.ctx->chain_mask & kbit) && ch <= r.ctx->chain_ch && nd <= 3 &&
+            g16_chain_supported(ch, rb.k, rb.dil.data(), nd)) {
+          r.clchain(rb, ch, xu, xs, bs, (int)Tout, j > 0, j == nk - 1 ? (float)nk : 1.f, nb);
+          continue;
+        }
         for (int d = 0; d < nd; ++d) {
           const bool last = d == nd - 1;
           const float div = (last && j == nk - 1) ? (float)nk : 1.f;
@@ -519,6 +560,9 @@ int vsp_create(const vsp_config* cfg, int device, vsp_ctx** out) {
   }
   if (const char* e = getenv("VSP_CHUNK_MB")) ctx->chunk_mb = atof(e);
   if (const char* e = getenv("VSP_FUSE_PAIRS")) ctx->fuse_pairs = atoi(e) != 0;
+  if (const char* e = getenv("VSP_CHAIN")) ctx->chain_mask = atoi(e);
+  if (const char* e = getenv("VSP_PAIR_IMPL")) ctx->pair_via_chain = std::strcmp(e, "chain") == 0;
+  if (const char* e = getenv("VSP_CHAIN_CH")) ctx->chain_ch = atoi(e);
   *out = ctx;  // returned even on failure so that vsp_last_error can be read; caller destroys it
   return rc;
 }

@@ -69,8 +69,15 @@ __device__ unsigned g_g16_stamp_count;
       g_g16_stamps[stamp_slot][stamp_n] = __builtin_amdgcn_s_memrealtime();             \
     ++stamp_n;                                                                          \
   } while (0)
+#define G16_STAMPT(tag)                                                                 \
+  do {                                                                                  \
+    if (stamp_slot >= 0 && stamp_n < G16_NSTAMP - 1 && lane == 0)                       \
+      g_g16_stamps[stamp_slot][stamp_n] = (__builtin_amdgcn_s_memrealtime() & 0x00ffffffffffffffull) | ((unsigned long long)(tag) << 56); \
+    ++stamp_n;                                                                          \
+  } while (0)
 #else
 #define G16_STAMP() ((void)0)
+#define G16_STAMPT(tag) ((void)0)
 #endif
 
 constexpr int G16_HALO = 64;   // max (K-1)*dil
@@ -793,6 +800,346 @@ hipError_t launch_g16_pair(const ClPairArgs& a, int B, hipStream_t s) {
     return a.C == 32 ? launch_g16_pair_tile<1, 2, 1, 8>(a, B, s) : launch_g16_pair_tile<2, 1, 1, 8>(a, B, s);
   if (nwv == 8) return a.C == 32 ? launch_g16_pair_tile<1, 2, 3, 8>(a, B, s) : launch_g16_pair_tile<2, 1, 3, 8>(a, B, s);
   return a.C == 32 ? launch_g16_pair_tile<1, 2, 3, 16>(a, B, s) : launch_g16_pair_tile<2, 1, 3, 16>(a, B, s);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Fused ResBlock1 CHAIN (reference modules.py:210-223, the whole loop `for c1, c2 in zip(convs1, convs2)`): np conv
+// pairs in ONE launch.  HBM sees x once and the result once (a pair launch per dilation moves 3 passes each); the
+// price is the chain's halo H = sum of the paddings of its 2 np convolutions, recomputed per side of every tile.
+//   * every convolution runs on the block's full BT columns with FIXED column <-> time mapping (column c = time
+//     tb + c): its input image sits in LDS with GRD guard rows on either side, a tap reads row c + tap * dil - pad.
+//     Columns within the accumulated padding of a tile edge compute garbage that never reaches a valid column
+//     (a D column depends on its own B column only); columns [H, BT - H) are exact and are the ones stored;
+//   * the running x_p lives in registers in D-tile layout (lane = column, four consecutive channels), so the
+//     residual add is lane-local and x is read from HBM exactly once; the images (leaky-relu, hi / lo split, zero
+//     outside the utterance = the reference's zero padding of EVERY convolution input) are written from registers;
+//   * weights stream through the 3-slot LDS-DMA ring as one sequence of slices over the 2 np convolutions.
+// Per output the arithmetic is that of g16_pair / g16_conv (chunk-major, tap-minor, HH / CROSS / CROSS, bias in the
+// accumulator, (hh + cr / 2048) + x): bit-identical to the pair-per-launch and conv-per-launch paths.
+template <int NCH, int NW, int G, int TERMS, int NWV>
+__global__ void __launch_bounds__(64 * NWV, 2) g16_chain(ClChainArgs a) {
+  constexpr int MW = 2 * NCH, C = 32 * NCH, CW = 16 * NW;   // CW = columns per wave
+  constexpr int BT = CW * NWV, GRD = G16_HALO / 2, WR = BT + G16_HALO, PL = WR * 16, XIMG = 4 * PL, XBUF = 2 * XIMG;
+  constexpr int TAPB = MW * 2048;               // bytes of one tap in a ring slot
+  constexpr int SLOT = G * TAPB;
+  constexpr int NS = 3;
+  constexpr int NPT = 2 * MW;                   // 1 KiB pieces per tap
+  constexpr int NBWMAX = (G * NPT + NWV - 1) / NWV;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* const Xw = lds;                         // NCH chunk images of the current convolution's input
+  char* const Rg = lds + NCH * XBUF;
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, q4 = lane >> 4, l15 = lane & 15;
+
+  // XCD-aware tile numbering: XCD k gets the k-th contiguous eighth of the (utterance, tile) sequence
+  const int nwg = gridDim.x, orig = blockIdx.x;
+  const int xcd = orig & 7, qd = nwg >> 3, rem = nwg & 7;
+  const int id = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (orig >> 3);
+  const int b = id / a.tiles, tile = id - b * a.tiles;
+
+#ifdef G16_STAMPS
+  int stamp_slot = -1, stamp_n = 0;
+  if (wave == 0 && orig % 97 == 5 && (a.terms & 0x100)) {
+    unsigned sl_ = 0;
+    if (lane == 0) sl_ = atomicAdd(&g_g16_stamp_count, 1u);
+    sl_ = __builtin_amdgcn_readfirstlane(sl_);
+    stamp_slot = sl_ < (unsigned)G16_NSAMPLE ? (int)sl_ : -1;
+  }
+  G16_STAMPT(1);
+#endif
+  const int K = a.K, p2 = (K - 1) >> 1, H = a.halo;
+  const int R = BT - 2 * H;                     // columns stored per block
+  const int tb = tile * R - H;                  // time of column 0
+  const int ns = (K + G - 1) / G;               // slices per chunk
+  const int S = 2 * a.np * NCH * ns;
+
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x) + (size_t)b * a.x_bs, 0, a.T * C * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)b * a.o_bs, 0, a.T * C * 4,
+                                                                      0x00020000);
+  const float slope = a.slope;
+
+  // ---- x_0 in D-tile layout; zero outside the utterance
+  bool tval[NW];
+  f32x4 xr[MW][NW];
+#pragma unroll
+  for (int j = 0; j < NW; ++j) {
+    const int t = tb + wave * CW + 16 * j + l15;
+    tval[j] = t >= 0 && t < a.T;
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+      xr[i][j] = (G16_DIAG & 16) ? f32x4{1.f, 2.f, 3.f, 4.f}
+                                 : g16_as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(
+                                       rx, tval[j] ? (t * C + 16 * i + 4 * q4) * 4 : G16_OOR, 0, 0));
+  }
+
+  // ---- weight slices: one sequence over the 2 np convolutions, chunk-major, G taps per slice
+  int dv = 0, dc = 0, dsl = 0;
+  auto dma_next = [&](int slot) -> int {
+    const uint4* Wg = reinterpret_cast<const uint4*>(a.w[dv]);
+    const int tap0 = dsl * G;
+    const int pieces = ((K - tap0) < G ? (K - tap0) : G) * NPT;
+    const size_t src = (G16_DIAG & 32) ? 0 : ((size_t)dc * K + tap0) * MW * 128;        // uint4 units
+    int mine = 0;
+#pragma unroll
+    for (int u = 0; u < NBWMAX; ++u) {
+      const int p = u * NWV + wave;
+      if (p < pieces && (G16_DIAG & 2) == 0) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wg + src + (size_t)p * 64 + lane),
+                                         (__attribute__((address_space(3))) void*)(Rg + slot * SLOT + p * 1024), 16, 0, 0);
+        ++mine;
+      }
+    }
+    if (++dsl == ns) { dsl = 0; if (++dc == NCH) { dc = 0; ++dv; } }
+    return mine;
+  };
+
+  // ---- image of a D-layout tile set: leaky-relu, split, zero outside the utterance.  A lane's four channels
+  //      16 i + 4 q4 .. + 3 sit in chunk i / 2, plane 2 (i & 1) + (q4 >> 1), at byte 8 (q4 & 1) of the row's 16.
+  auto write_image = [&](const f32x4 (&v)[MW][NW]) {
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+      for (int j = 0; j < NW; ++j) {
+        f16x4 eh, el;
+        g16_split4(tval[j] ? v[i][j] : f32x4{0.f, 0.f, 0.f, 0.f}, slope, true, eh, el);
+        char* dst = Xw + (i >> 1) * XBUF + (2 * (i & 1) + (q4 >> 1)) * PL + (GRD + wave * CW + 16 * j + l15) * 16 + 8 * (q4 & 1);
+        *reinterpret_cast<f16x4*>(dst) = eh;
+        if constexpr (TERMS == 3) *reinterpret_cast<f16x4*>(dst + XIMG) = el;
+      }
+  };
+
+  // ---- convolution main loop.  One STEP = one (chunk, tap): 2 MW A fragments (weights, from the ring) and 2 NW B
+  //      fragments (image rows shifted by tap * dilation), MW * NW * 3 MFMAs.  Software pipeline inside every wave:
+  //      the A fragments are double-buffered in registers (step s + 1 requested before the MFMAs of step s), the B
+  //      fragments of an n-tile are re-requested in place right after its last MFMA of the step has issued; the
+  //      waits are counted (LDS returns in order), so a wave's matrix work runs in the shadow of its own reads and
+  //      the 4 waves of a SIMD do not have to find each other in different phases.
+  //      Ring: slices n, n + 1, n + 2 are resident or in flight.  retire(): every wave has its last fragments of
+  //      slice n in registers -> wait for slice n + 1, barrier, request slice n + 3 into the freed slot.  Inside a
+  //      convolution this happens at the START of the slice's last step (whose fragments were requested a step ago).
+  constexpr int RA = MW * (TERMS == 3 ? 2 : 1), RB = TERMS == 3 ? 2 : 1;   // LDS reads per A set / per n-tile
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  const unsigned wa_lane = lds0 + NCH * XBUF + lane * 16;
+  constexpr int gs = G;                         // taps per slice (the last one of a chunk may be shorter)
+  f16x8 Ah[2][MW], Al[2][MW], Bh[NW], Bl[NW];
+  f32x4 hh[MW][NW], cr[MW][NW];
+
+  int n_cur = 0, n_issued = 0, pc_last = 0;     // slice being read; slices requested; my pieces of the youngest one
+  auto issue_slice = [&]() {
+    if (n_issued < S) { pc_last = dma_next(n_issued % NS); ++n_issued; }
+  };
+  auto wait_landed = [&](int n) {               // slice n (< n_issued) has landed: younger are n + 1 .. n_issued - 1
+    const int younger = n_issued - 1 - n;
+    if (younger <= 0) g16_vmcnt<0>();
+    else if (younger == 1) { if (pc_last == 0) g16_vmcnt<0>(); else if (pc_last == 1) g16_vmcnt<1>(); else g16_vmcnt<2>(); }
+    else { if (pc_last == 0) g16_vmcnt<0>(); else g16_vmcnt<1>(); }   // (stricter than needed: the older one's count is not kept)
+  };
+  auto retire = [&]() {
+    if (n_cur + 1 < S) {
+      G16_STAMPT(11);
+      wait_landed(n_cur + 1);
+      G16_STAMPT(16);
+      G16_BARRIER();
+      G16_STAMPT(17);
+      issue_slice();
+      G16_STAMPT(12);
+    }
+    ++n_cur;
+  };
+  auto read_a = [&](auto P, unsigned a_addr) {
+    constexpr int pp = decltype(P)::value;
+    g16_for<MW>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      Ah[pp][i] = g16_lds_read<i * 2048>(a_addr);
+      if constexpr (TERMS == 3) Al[pp][i] = g16_lds_read<i * 2048 + 1024>(a_addr);
+    });
+  };
+  auto read_b = [&](auto J, unsigned b_addr) {
+    constexpr int j = decltype(J)::value;
+    Bh[j] = g16_lds_read<j * 256>(b_addr);
+    if constexpr (TERMS == 3) Bl[j] = g16_lds_read<j * 256 + XIMG>(b_addr);
+  };
+  auto mfma_col = [&](auto P, auto J) {
+    constexpr int pp = decltype(P)::value, j = decltype(J)::value;
+    __builtin_amdgcn_sched_barrier(0);
+    g16_for<MW>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      hh[i][j] = G16_MFMA(Ah[pp][i], Bh[j], hh[i][j]);
+      if constexpr (TERMS == 3) {
+        cr[i][j] = G16_MFMA(Al[pp][i], Bh[j], cr[i][j]);
+        cr[i][j] = G16_MFMA(Ah[pp][i], Bl[j], cr[i][j]);
+      }
+    });
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // one convolution over the image in Xw: dilation `rowstep`, bias b; result in hh / cr.  On entry the image and
+  // slice n_cur (the convolution's first) are visible to every wave.
+  auto conv = [&](const float* bias, int rowstep) {
+#pragma unroll
+    for (int i = 0; i < MW; ++i) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 16 * i + 4 * q4);
+#pragma unroll
+      for (int j = 0; j < NW; ++j) { hh[i][j] = bv; cr[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
+    const unsigned xb0 = lds0 + q4 * PL + (GRD + wave * CW + l15 - rowstep * p2) * 16;
+    const int steps = NCH * K;
+    int chunk = 0, tap = 0, gtap = 0;             // of the step being multiplied; gtap = tap within its slice
+    unsigned a_addr = wa_lane + (n_cur % NS) * SLOT, b_addr = xb0;
+    read_a(std::integral_constant<int, 0>{}, a_addr);
+    g16_for<NW>([&](auto J) { read_b(J, b_addr); });
+    G16_STAMPT(10);
+    auto step = [&](auto P, int st) {
+      constexpr int pp = decltype(P)::value;
+      if (st + 1 < steps) {
+        const bool slice_end = gtap == gs - 1 || tap == K - 1;
+        if (slice_end) retire();                        // (the barrier drains this wave's reads: the counted waits below still hold)
+        const bool chunk_end = tap == K - 1;
+        chunk = chunk_end ? chunk + 1 : chunk;
+        tap = chunk_end ? 0 : tap + 1;
+        gtap = slice_end ? 0 : gtap + 1;
+        a_addr = wa_lane + (n_cur % NS) * SLOT + gtap * TAPB;
+        b_addr = xb0 + chunk * XBUF + tap * rowstep * 16;
+      }
+      // (the last step of a convolution re-requests its own fragments: one code path, uniform counted waits)
+      read_a(std::integral_constant<int, 1 - pp>{}, a_addr);
+      g16_for<NW>([&](auto J) {
+        // in flight behind the fragments this n-tile needs: the other n-tiles' refills and the next A set
+        g16_lgkmcnt<RA + (NW - 1) * RB>();
+        mfma_col(P, J);
+        read_b(J, b_addr);
+      });
+    };
+    for (int st = 0; st < steps; st += 2) {
+      step(std::integral_constant<int, 0>{}, st);
+      if (st + 1 < steps) step(std::integral_constant<int, 1>{}, st + 1);
+    }
+    // nothing may still be writing the fragment registers when the compiler reuses them
+    g16_lgkmcnt<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    G16_STAMPT(13);
+#pragma unroll
+    for (int i = 0; i < MW; ++i) asm volatile("" ::"v"(Ah[0][i]), "v"(Ah[1][i]), "v"(Al[0][i]), "v"(Al[1][i]));
+#pragma unroll
+    for (int j = 0; j < NW; ++j) asm volatile("" ::"v"(Bh[j]), "v"(Bl[j]));
+  };
+  auto result = [&](int i, int j) -> f32x4 {
+    if constexpr (TERMS == 3) return hh[i][j] + cr[i][j] * (1.f / 2048.f);
+    else return hh[i][j];
+  };
+
+  issue_slice(); issue_slice(); issue_slice();
+  write_image(xr);
+  G16_STAMPT(2);
+  wait_landed(0);
+  G16_BARRIER();
+  G16_STAMPT(3);
+  const int ncv = 2 * a.np;
+  for (int cv = 0; cv < ncv; ++cv) {
+    const bool second = cv & 1;
+    conv(a.b[cv], second ? 1 : a.dil[cv >> 1]);
+    if (cv + 1 == ncv) break;
+    f32x4 nx[MW][NW];                                  // the next convolution's input: conv1's output or the new x
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+      for (int j = 0; j < NW; ++j) {
+        nx[i][j] = result(i, j);
+        if (second) { nx[i][j] += xr[i][j]; xr[i][j] = nx[i][j]; }
+      }
+    retire();                                          // also: nobody still reads the image
+    write_image(nx);
+    G16_STAMPT(14);
+    G16_BARRIER();
+    G16_STAMPT(15);
+  }
+  G16_STAMPT(20);
+
+  // ---- epilogue: out = conv2 + x_{np-1} (+ previous resblock sum) (/ div) on the exact columns
+#pragma unroll
+  for (int i = 0; i < MW; ++i)
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int col = wave * CW + 16 * j + l15;
+      const int t = tb + col;
+      const int off = (col >= H && col < H + R && t < a.T) ? (t * C + 16 * i + 4 * q4) * 4 : G16_OOR;
+      f32x4 v = result(i, j);
+      v += xr[i][j];
+      if (a.acc_prev) v += g16_as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(ro, off, 0, 0));
+      if (a.div != 1.f) v /= a.div;
+      if ((G16_DIAG & 8) == 0) __builtin_amdgcn_raw_buffer_store_b128(g16_as_u32x4(v), ro, off, 0, 0);
+    }
+#ifdef G16_STAMPS
+  G16_STAMPT(21);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  G16_STAMPT(22);
+#endif
+}
+
+template <int NCH, int NW, int G, int TERMS, int NWV>
+static hipError_t launch_g16_chain_tile(ClChainArgs a, int B, hipStream_t s) {
+  constexpr int BT = 16 * NW * NWV;
+  constexpr size_t lds = (size_t)NCH * 2 * 4 * (BT + G16_HALO) * 16 + (size_t)3 * G * 2 * NCH * 2048;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  static bool attr_set = false;
+  auto kern = g16_chain<NCH, NW, G, TERMS, NWV>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int R = BT - 2 * a.halo;
+  if (R < 32) return hipErrorInvalidValue;
+  a.tiles = (a.T + R - 1) / R;
+  const long n = (long)a.tiles * B;
+  if (n <= 0 || n > 0x7fffffffL) return hipErrorInvalidValue;
+#ifdef G16_STAMPS
+  {  // stamps only in the VSP_STAMP_CHAIN-th chain launch of this shape (0-based)
+    static int launch_no = 0;
+    static int target = -2;
+    if (target == -2) { const char* e = getenv("VSP_STAMP_CHAIN"); target = e ? atoi(e) : -1; }
+    if (launch_no++ == target) a.terms |= 0x100;
+  }
+#endif
+  hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(64 * NWV), lds, s, a);
+  return hipGetLastError();
+}
+
+static int g16_chain_halo(int K, const int* dil, int np) {
+  int h = 0;
+  for (int p = 0; p < np; ++p) h += (dil[p] + 1) * ((K - 1) / 2);
+  return h;
+}
+
+bool g16_chain_supported(int C, int K, const int* dil, int np) {
+  if (!(C == 32 || C == 64) || np < 1 || np > 3 || K < 1 || !(K & 1)) return false;
+  for (int p = 0; p < np; ++p)
+    if (dil[p] < 1 || dil[p] * ((K - 1) / 2) > G16_HALO / 2) return false;
+  return 256 - 2 * g16_chain_halo(K, dil, np) >= 32;
+}
+
+hipError_t launch_g16_chain(const ClChainArgs& a0, int B, hipStream_t s) {
+  ClChainArgs a = a0;
+  if (!g16_chain_supported(a.C, a.K, a.dil, a.np) || a.T <= 0 || B <= 0 || (a.x_bs & 3) || (a.o_bs & 3) ||
+      (reinterpret_cast<uintptr_t>(a.x) & 15) || (reinterpret_cast<uintptr_t>(a.out) & 15) || a.x == a.out)
+    return hipErrorInvalidValue;
+  a.halo = g16_chain_halo(a.K, a.dil, a.np);
+  // few, fat waves (64 columns x all channels each, up to 256 registers).  32 channels: one 8-wave block of 512
+  // columns per CU when the halo would eat more than a quarter of a 256-column tile, else two 4-wave blocks of 256
+  // columns (their convolution hand-offs overlap); VSP_CHAIN_WAVES=4|8 forces one shape
+  static int force = -1;
+  if (force < 0) { const char* e = getenv("VSP_CHAIN_WAVES"); force = e ? atoi(e) : 0; }
+  const bool wide = a.C == 32 && (force ? force == 8 : 2 * a.halo > 64);
+  // <NCH, NW, G, TERMS, NWV>
+  if (a.terms == 1) {
+    if (a.C == 64) return launch_g16_chain_tile<2, 2, 2, 1, 8>(a, B, s);
+    return wide ? launch_g16_chain_tile<1, 4, 4, 1, 8>(a, B, s) : launch_g16_chain_tile<1, 4, 2, 1, 4>(a, B, s);
+  }
+  if (a.C == 64) return launch_g16_chain_tile<2, 2, 2, 3, 8>(a, B, s);
+  return wide ? launch_g16_chain_tile<1, 4, 4, 3, 8>(a, B, s) : launch_g16_chain_tile<1, 4, 2, 3, 4>(a, B, s);
 }
 
 }  // namespace vsp

@@ -75,6 +75,22 @@ struct ClPairArgs {
   int tiles;                                // set by the launcher: tiles per utterance
   int xrows;                                // set by the launcher: staged window rows
 };
+// Fused ResBlock1 CHAIN on channels-last activations (gen16.hip): np conv pairs back to back in one launch,
+//   x_{p+1} = x_p + conv2_p(lrelu(conv1_p(lrelu(x_p), dil_p) + b1_p), 1) + b2_p,   out = x_np [+ out] [/ div];  x != out.
+// The running x_p stays in registers (fp32), the convolution inputs in LDS; a block recomputes the chain's halo.
+struct ClChainArgs {
+  const float* x; long x_bs;
+  float* out; long o_bs;
+  const uint16_t* w[6]; const float* b[6];  // conv1, conv2 of pair 0, 1, 2
+  int dil[3]; int np;
+  int C, K, T;
+  float slope;
+  int acc_prev; float div;
+  int terms;
+  int tiles, halo;                          // set by the launcher: tiles per utterance, columns recomputed per side
+};
+bool g16_chain_supported(int C, int K, const int* dil, int np);
+hipError_t launch_g16_chain(const ClChainArgs& a, int B, hipStream_t s);
 hipError_t launch_g16_conv(const ClConvArgs& a, int B, hipStream_t s);
 bool g16_pair_supported(int C, int K, int dil);
 hipError_t launch_g16_pair(const ClPairArgs& a, int B, hipStream_t s);
