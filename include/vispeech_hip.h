@@ -245,6 +245,30 @@ int vsp_has_voice_conversion(const vsp_ctx* ctx);
 int vsp_rq_spline(void* stream, int64_t n, int nb, const float* x, const float* uw, const float* uh,
                   const float* ud, int inverse, float tail_bound, float* y, float* logabsdet);
 
+/* ---- vocoder operators, stand-alone (no context) ------------------------------------------ */
+/* The channels-last split-f16 convolution kernels of the generator as plain operators, for unit parity
+ * and for callers that hold their own weights.  Activations are device pointers, fp32, channels-last
+ * [B][T][C]; weights and biases are HOST pointers in the reference's dense layout (torch.nn.Conv1d
+ * weight [Cout][Cin][K], weight-norm already folded); they are packed into fragment order and uploaded
+ * inside the call, which synchronises the stream before it returns (these are not the fast path:
+ * vsp_generator keeps its weights packed in the arena).  terms = 3: fp32-accurate split products,
+ * 1: plain f16 operands.
+ *
+ * vsp_cl_conv1d: out = conv1d(lrelu(x, in_slope), w, dilation, padding = dilation (K - 1) / 2) + bias
+ * [+ res]; in_slope = 1 applies no activation (reference modules.py:214-221: F.leaky_relu + Conv1d).
+ * Cin % 32 == 0, Cout % 32 == 0, K odd, (K - 1) * dilation <= 64. */
+int vsp_cl_conv1d(void* stream, int B, int T, int Cin, int Cout, int K, int dilation, const float* x,
+                  const float* w_host, const float* bias_host, float in_slope, const float* res, int terms,
+                  float* out);
+/* vsp_cl_resblock: ResBlock1.forward without the mask (reference modules.py:210-223):
+ *   for p < n_pairs:  x = x + conv2_p(lrelu(conv1_p(lrelu(x), dilations[p]))), slope 0.1
+ * w_host[2 p], w_host[2 p + 1] = conv1_p, conv2_p dense [C][C][K]; bias_host likewise [C].
+ * mode 0: one launch per convolution (g16_conv), any C % 32 == 0;
+ * mode 1: one launch per pair (g16_pair), C = 32 or 64;  mode 2: ONE launch (g16_chain), C = 32 or 64,
+ * n_pairs <= 3.  The three modes return identical bits.  x != out. */
+int vsp_cl_resblock(void* stream, int B, int T, int C, int K, int n_pairs, const int* dilations, const float* x,
+                    const float* const* w_host, const float* const* bias_host, int mode, int terms, float* out);
+
 /* ---- measurement -------------------------------------------------------------------------- */
 /* When enabled, every launch of a profiled class is bracketed by a HIP event pair on the launch
  * stream.  vsp_profile_read_class synchronises those events and returns, since the last reset, for

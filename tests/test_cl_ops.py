@@ -1,0 +1,121 @@
+"""Unit parity of the generator's hot kernels through the stand-alone C-ABI operators (vsp_cl_conv1d,
+vsp_cl_resblock): g16_conv, g16_pair and g16_chain against torch's fp32/fp64 CPU convolution on shapes the
+fixed model configuration never produces -- every channel width / kernel size / dilation the kernels accept, time
+lengths around the tile edges (1, 255, 256, 257, ...), ragged batches of one.  The three ResBlock implementations
+must agree bit for bit.  Reference semantics: modules.py:210-223 (ResBlock1), torch.nn.Conv1d."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5          # relative to max|ref| (SURVEY 8c stage gate); measured ~1e-7 .. 5e-7
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from vispeech_amd import _lib
+    return _lib.lib()
+
+
+def P(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def host_ptrs(arrs):
+    return (C.c_void_p * len(arrs))(*[a.ctypes.data_as(C.c_void_p) for a in arrs])
+
+
+@pytest.mark.parametrize("cin,cout,k,dil", [(32, 32, 3, 1), (64, 32, 7, 3), (128, 128, 11, 5), (256, 128, 3, 5),
+                                            (128, 256, 7, 1), (32, 64, 1, 1), (512, 256, 3, 1), (64, 96, 5, 2)])
+@pytest.mark.parametrize("b,t", [(1, 1), (2, 255), (1, 256), (3, 257), (1, 700)])
+def test_cl_conv1d_matches_torch(lib, cin, cout, k, dil, b, t):
+    r = np.random.Generator(np.random.PCG64(cin * 1000 + cout + k + dil + t))
+    x = r.standard_normal((b, t, cin)).astype(np.float32)
+    w = (r.standard_normal((cout, cin, k)) / np.sqrt(cin * k)).astype(np.float32)
+    bias = r.standard_normal(cout).astype(np.float32)
+    res = r.standard_normal((b, t, cout)).astype(np.float32)
+    xd, rd = torch.from_numpy(x).cuda(), torch.from_numpy(res).cuda()
+    out = torch.empty(b, t, cout, device="cuda")
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for slope, use_res in ((0.1, True), (1.0, False)):
+        rc = lib.vsp_cl_conv1d(stream, b, t, cin, cout, k, dil, P(xd), w.ctypes.data_as(C.c_void_p),
+                               bias.ctypes.data_as(C.c_void_p), slope, P(rd) if use_res else None, 3, P(out))
+        assert rc == 0
+        xt = torch.from_numpy(x).double().transpose(1, 2)
+        if slope != 1.0:
+            xt = F.leaky_relu(xt, slope)
+        ref = F.conv1d(xt, torch.from_numpy(w).double(), torch.from_numpy(bias).double(), dilation=dil,
+                       padding=dil * (k - 1) // 2).transpose(1, 2)
+        if use_res:
+            ref = ref + torch.from_numpy(res).double()
+        assert rel_err(out.cpu().numpy(), ref.numpy()) <= TOL, (slope, use_res)
+
+
+def torch_resblock(x, ws, bs, dils, k):
+    y = torch.from_numpy(x).double().transpose(1, 2)
+    for p, d in enumerate(dils):
+        t = F.leaky_relu(y, 0.1)
+        t = F.conv1d(t, torch.from_numpy(ws[2 * p]).double(), torch.from_numpy(bs[2 * p]).double(), dilation=d,
+                     padding=d * (k - 1) // 2)
+        t = F.leaky_relu(t, 0.1)
+        t = F.conv1d(t, torch.from_numpy(ws[2 * p + 1]).double(), torch.from_numpy(bs[2 * p + 1]).double(),
+                     padding=(k - 1) // 2)
+        y = t + y
+    return y.transpose(1, 2).numpy()
+
+
+@pytest.mark.parametrize("c,k,dils", [(32, 3, (1, 3, 5)), (32, 7, (1, 3, 5)), (32, 11, (1, 3, 5)), (64, 3, (1, 3, 5)),
+                                      (64, 7, (1, 3)), (64, 11, (5,)), (32, 5, (2, 1, 4)), (32, 3, (1,))])
+@pytest.mark.parametrize("b,t", [(1, 1), (2, 131), (1, 256), (2, 489), (1, 1500)])
+def test_cl_resblock_three_implementations(lib, c, k, dils, b, t):
+    r = np.random.Generator(np.random.PCG64(c + 10 * k + 100 * len(dils) + t))
+    x = r.standard_normal((b, t, c)).astype(np.float32)
+    ws = [(r.standard_normal((c, c, k)) / np.sqrt(c * k)).astype(np.float32) for _ in range(2 * len(dils))]
+    bs = [r.standard_normal(c).astype(np.float32) * 0.1 for _ in range(2 * len(dils))]
+    xd = torch.from_numpy(x).cuda()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    darr = (C.c_int * len(dils))(*dils)
+    outs = []
+    for mode in (0, 1, 2):
+        out = torch.full((b, t, c), float("nan"), device="cuda")
+        rc = lib.vsp_cl_resblock(stream, b, t, c, k, len(dils), darr, P(xd), host_ptrs(ws), host_ptrs(bs), mode, 3, P(out))
+        assert rc == 0, mode
+        outs.append(out.cpu())
+    ref = torch_resblock(x, ws, bs, dils, k)
+    assert rel_err(outs[0].numpy(), ref) <= TOL
+    assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
+    assert torch.equal(outs[0], outs[2]), float((outs[0] - outs[2]).abs().max())
+
+
+def test_cl_ops_refuse_what_they_cannot_do(lib):
+    x = torch.zeros(1, 8, 48, device="cuda")
+    out = torch.zeros(1, 8, 48, device="cuda")
+    w = np.zeros((48, 48, 3), dtype=np.float32)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.vsp_cl_conv1d(stream, 1, 8, 48, 48, 3, 1, P(x), w.ctypes.data_as(C.c_void_p), None, 1.0, None, 3, P(out)) == -7   # channels % 32
+    x = torch.zeros(1, 8, 32, device="cuda")
+    out = torch.zeros(1, 8, 32, device="cuda")
+    w = np.zeros((32, 32, 4), dtype=np.float32)
+    assert lib.vsp_cl_conv1d(stream, 1, 8, 32, 32, 4, 1, P(x), w.ctypes.data_as(C.c_void_p), None, 1.0, None, 3, P(out)) == -7   # even K
+    w = np.zeros((32, 32, 3), dtype=np.float32)
+    assert lib.vsp_cl_conv1d(stream, 1, 8, 32, 32, 3, 40, P(x), w.ctypes.data_as(C.c_void_p), None, 1.0, None, 3, P(out)) == -7  # halo
+    assert lib.vsp_cl_conv1d(stream, 1, 8, 32, 32, 3, 1, P(x), w.ctypes.data_as(C.c_void_p), None, 1.0, None, 2, P(out)) == -1   # terms
+    d = (C.c_int * 1)(1)
+    assert lib.vsp_cl_resblock(stream, 1, 8, 32, 3, 1, d, P(x), host_ptrs([w, w]), host_ptrs([w, w]), 2, 3, P(x)) == -1          # in place
+    x128 = torch.zeros(1, 8, 128, device="cuda")
+    o128 = torch.zeros(1, 8, 128, device="cuda")
+    w128 = np.zeros((128, 128, 3), dtype=np.float32)
+    assert lib.vsp_cl_resblock(stream, 1, 8, 128, 3, 1, d, P(x128), host_ptrs([w128, w128]), host_ptrs([w128, w128]), 1, 3, P(o128)) == -7   # pairs: 32 / 64 channels
+    assert lib.vsp_cl_resblock(stream, 1, 0, 32, 3, 1, d, P(x), host_ptrs([w, w]), host_ptrs([w, w]), 2, 3, P(out)) == 0         # empty

@@ -11,7 +11,7 @@ rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if 'conv_post' in r['Kernel_Name']]
 seg = rows[idx[-2] + 1: idx[-1] + 1]
-gen = [r for r in seg if any(k in r['Kernel_Name'] for k in ('cl_conv', 'respair', 'g16_conv', 'g16_pair'))]
+gen = [r for r in seg if any(k in r['Kernel_Name'] for k in ('g16_conv', 'g16_pair', 'g16_chain'))]
 c0 = 512
 rates = [8, 8, 4, 2]; uk = [16, 16, 4, 4]; ks = [3, 7, 11]
 specs = []
@@ -27,16 +27,29 @@ for i in range(4):
             else:
                 specs.append((f's{i}k{k}d{d}a', 'conv', cout, cout, k, t, t, 0))
                 specs.append((f's{i}k{k}d1b', 'conv', cout, cout, k, t, t, 1))
-if len(gen) != len(specs):
-    print(f"# note: {len(gen)} launches vs {len(specs)} expected")
+# a g16_chain launch covers all dilation pairs of one ResBlock: merge their specs
+merged = []
+gi = 0
+si = 0
+while si < len(specs) and gi < len(gen):
+    name, kind, co, ci, K, N, Nout, res = specs[si]
+    if 'g16_chain' in gen[gi]['Kernel_Name'] and kind == 'pair':
+        merged.append((name[:-2] + 'ch', 'chain', co, ci, K, N, Nout, res, 3))
+        si += 3
+    else:
+        merged.append((name, kind, co, ci, K, N, Nout, res, 1))
+        si += 1
+    gi += 1
+if len(gen) != len(merged) or si != len(specs):
+    print(f"# note: {len(gen)} launches vs {len(merged)} expected")
 tot = 0
 stage = {}
-for (name, kind, co, ci, K, N, Nout, res), r in zip(specs, gen):
+for (name, kind, co, ci, K, N, Nout, res, npair), r in zip(merged, gen):
     dur = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6
-    if kind == 'pair':
-        fl = 2 * 2.0 * co * ci * K * N * B
-        byt = 4.0 * B * N * co * 5           # layer-boundary model of the two convs
-        real = 4.0 * B * N * co * 3          # x in, residual x, y out
+    if kind in ('pair', 'chain'):
+        fl = npair * 2 * 2.0 * co * ci * K * N * B
+        byt = npair * 4.0 * B * N * co * 5   # layer-boundary model of the convolutions the launch replaces (+ residual reads)
+        real = 4.0 * B * N * co * (2 if kind == 'chain' else 3)   # x in, residual x (a chain: none), y out
     else:
         fl = 2.0 * co * ci * K * N * B
         byt = 4.0 * B * (N * ci + Nout * co * (1 + res))
@@ -44,7 +57,7 @@ for (name, kind, co, ci, K, N, Nout, res), r in zip(specs, gen):
     tot += dur
     key = name[:2] if name[0] == 's' else name
     stage[key] = stage.get(key, 0) + dur
-    print(f"{name:10s} {kind:4s} C={co:4d} K={K:2d} rows={N:7d} {dur:7.3f} ms  alg {fl/dur/1e9:6.1f} TF/s  mfma-issue "
+    print(f"{name:10s} {kind:5s} C={co:4d} K={K:2d} rows={N:7d} {dur:7.3f} ms  alg {fl/dur/1e9:6.1f} TF/s  mfma-issue "
           f"{3*fl/dur/1e9/2500*100:5.1f}%  alg {byt/dur/1e6:7.1f} GB/s  moved>= {real/dur/1e6:7.1f} GB/s  vgpr={r['VGPR_Count']}")
 print('per stage ms:', {k: round(v, 2) for k, v in stage.items()})
 print(f'total {tot:.2f} ms')

@@ -1380,6 +1380,118 @@ int vsp_rq_spline(void* stream, int64_t n, int nb, const float* x, const float* 
   return e == hipSuccess ? VSP_OK : (e == hipErrorInvalidValue ? VSP_ERR_UNSUPPORTED : VSP_ERR_HIP);
 }
 
+// -------------------------------------------------------------------------------------------- stand-alone vocoder operators
+namespace {
+struct DevBuf {           // hipMalloc'd scratch of one stand-alone call
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+};
+// dense [Cout][Cin][K] host weights -> packed fragment image on the device; bias -> device
+hipError_t upload_cl_conv(const float* w_host, const float* bias_host, int Cout, int Cin, int K, DevBuf& w, DevBuf& bias,
+                          hipStream_t s) {
+  std::vector<uint16_t> packed(packed_g16_halfs(Cout, Cin, K));
+  pack_g16_weights(packed.data(), Cout, Cin, K, w_host);
+  hipError_t e = w.alloc(packed.size() * 2);
+  if (e == hipSuccess) e = bias.alloc((size_t)Cout * 4);
+  if (e == hipSuccess) e = hipMemcpyAsync(w.p, packed.data(), packed.size() * 2, hipMemcpyHostToDevice, s);
+  std::vector<float> zero;
+  if (!bias_host) { zero.assign(Cout, 0.f); bias_host = zero.data(); }
+  if (e == hipSuccess) e = hipMemcpyAsync(bias.p, bias_host, (size_t)Cout * 4, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);     // the host vectors die with this frame
+  return e;
+}
+ClConvArgs cl_conv_args(const float* x, int T, int Cin, int Cout, int K, int dil, const DevBuf& w, const DevBuf& bias,
+                        float in_slope, const float* res, int terms, float* out) {
+  ClConvArgs a;
+  std::memset(&a, 0, sizeof a);
+  a.x = x; a.x_bs = (long)T * Cin; a.x_ts = Cin;
+  a.wh = static_cast<const uint16_t*>(w.p); a.bias = static_cast<const float*>(bias.p);
+  a.out = out; a.o_bs = (long)T * Cout; a.o_ts = Cout;
+  a.res = res; a.r_bs = (long)T * Cout; a.r_ts = Cout;
+  a.Cin = Cin; a.Cout = Cout; a.K = K; a.dil = dil; a.pad = dil * (K - 1) / 2;
+  a.T_in = T; a.Nq = T; a.T_store = T;
+  a.in_act = 1; a.in_slope = in_slope;
+  a.acc_prev = 0; a.div = 1.f; a.phases = 1; a.ups_p = 0;
+  a.terms = terms;
+  return a;
+}
+int op_rc(hipError_t e) { return e == hipSuccess ? VSP_OK : (e == hipErrorInvalidValue ? VSP_ERR_UNSUPPORTED : VSP_ERR_HIP); }
+}  // namespace
+
+int vsp_cl_conv1d(void* stream, int B, int T, int Cin, int Cout, int K, int dilation, const float* x, const float* w_host,
+                  const float* bias_host, float in_slope, const float* res, int terms, float* out) {
+  if (!x || !w_host || !out || B < 0 || T < 0 || (terms != 1 && terms != 3)) return VSP_ERR_ARG;
+  if (Cin <= 0 || Cout <= 0 || Cin % 32 || Cout % 32 || K < 1 || !(K & 1) || dilation < 1 || (K - 1) * dilation > 64 ||
+      (size_t)T * std::max(Cin, Cout) * 4 >= (size_t)1 << 31)
+    return VSP_ERR_UNSUPPORTED;
+  if (B == 0 || T == 0) return VSP_OK;
+  hipStream_t s = (hipStream_t)stream;
+  DevBuf w, bias;
+  hipError_t e = upload_cl_conv(w_host, bias_host, Cout, Cin, K, w, bias, s);
+  if (e == hipSuccess) e = launch_g16_conv(cl_conv_args(x, T, Cin, Cout, K, dilation, w, bias, in_slope, res, terms, out), B, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  return op_rc(e);
+}
+
+int vsp_cl_resblock(void* stream, int B, int T, int C, int K, int n_pairs, const int* dilations, const float* x,
+                    const float* const* w_host, const float* const* bias_host, int mode, int terms, float* out) {
+  if (!x || !w_host || !bias_host || !dilations || !out || x == out || B < 0 || T < 0 || n_pairs < 1 || n_pairs > 8 ||
+      mode < 0 || mode > 2 || (terms != 1 && terms != 3))
+    return VSP_ERR_ARG;
+  if (C <= 0 || C % 32 || K < 1 || !(K & 1) || (size_t)T * C * 4 >= (size_t)1 << 31) return VSP_ERR_UNSUPPORTED;
+  for (int p = 0; p < n_pairs; ++p) {
+    if (dilations[p] < 1 || (K - 1) * dilations[p] > 64) return VSP_ERR_UNSUPPORTED;
+    if (mode == 1 && !g16_pair_supported(C, K, dilations[p])) return VSP_ERR_UNSUPPORTED;
+    if (!w_host[2 * p] || !w_host[2 * p + 1]) return VSP_ERR_ARG;
+  }
+  if (mode == 2 && (n_pairs > 3 || !g16_chain_supported(C, K, dilations, n_pairs))) return VSP_ERR_UNSUPPORTED;
+  if (B == 0 || T == 0) return VSP_OK;
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<DevBuf> w(2 * n_pairs), bias(2 * n_pairs);
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < 2 * n_pairs && e == hipSuccess; ++i) e = upload_cl_conv(w_host[i], bias_host[i], C, C, K, w[i], bias[i], s);
+  const size_t el = (size_t)B * T * C;
+  DevBuf t1, ya, yb;
+  if (e == hipSuccess && mode != 2) e = t1.alloc(el * 4);
+  if (e == hipSuccess && mode != 2) e = ya.alloc(el * 4);
+  if (e == hipSuccess && mode != 2) e = yb.alloc(el * 4);
+  if (e != hipSuccess) return op_rc(e);
+  if (mode == 2) {
+    ClChainArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.x = x; a.x_bs = (long)T * C; a.out = out; a.o_bs = (long)T * C;
+    for (int i = 0; i < 2 * n_pairs; ++i) { a.w[i] = static_cast<const uint16_t*>(w[i].p); a.b[i] = static_cast<const float*>(bias[i].p); }
+    for (int p = 0; p < n_pairs; ++p) a.dil[p] = dilations[p];
+    a.np = n_pairs; a.C = C; a.K = K; a.T = T; a.slope = 0.1f; a.acc_prev = 0; a.div = 1.f; a.terms = terms;
+    e = launch_g16_chain(a, B, s);
+  } else {
+    // the running y ping-pongs between two buffers (a tile reads halo rows its neighbour writes)
+    const float* yin = x;
+    for (int p = 0; p < n_pairs && e == hipSuccess; ++p) {
+      float* yout = p == n_pairs - 1 ? out : static_cast<float*>((p & 1) ? yb.p : ya.p);
+      if (mode == 1) {
+        ClPairArgs a;
+        std::memset(&a, 0, sizeof a);
+        a.x = yin; a.x_bs = (long)T * C; a.out = yout; a.o_bs = (long)T * C;
+        a.w1h = static_cast<const uint16_t*>(w[2 * p].p); a.w2h = static_cast<const uint16_t*>(w[2 * p + 1].p);
+        a.b1 = static_cast<const float*>(bias[2 * p].p); a.b2 = static_cast<const float*>(bias[2 * p + 1].p);
+        a.C = C; a.K = K; a.dil = dilations[p]; a.T = T; a.slope = 0.1f; a.acc_prev = 0; a.div = 1.f; a.terms = terms;
+        e = launch_g16_pair(a, B, s);
+      } else {
+        e = launch_g16_conv(cl_conv_args(yin, T, C, C, K, dilations[p], w[2 * p], bias[2 * p], 0.1f, nullptr, terms,
+                                         static_cast<float*>(t1.p)), B, s);
+        if (e == hipSuccess)
+          e = launch_g16_conv(cl_conv_args(static_cast<const float*>(t1.p), T, C, C, K, 1, w[2 * p + 1], bias[2 * p + 1], 0.1f,
+                                           yin, terms, yout), B, s);
+      }
+      yin = yout;
+    }
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  return op_rc(e);
+}
+
 // -------------------------------------------------------------------------------------------- profiling
 int vsp_profile_enable(vsp_ctx* ctx, int on) {
   if (!ctx) return VSP_ERR_ARG;
