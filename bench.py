@@ -313,7 +313,7 @@ def main():
                     {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": f_hbm})
             roof.update({
                 "traffic": None,
-                "kernel": "generator convolutions (g16_conv + g16_pair, fused ResBlock pairs on the 64/32-channel stages), rank 0",
+                "kernel": "generator convolutions (g16_conv; g16_pair / g16_chain: fused ResBlock pairs / whole ResBlocks on the 64/32-channel stages), rank 0",
                 "launches": g["launches"], "kernel_ms_per_step": g["ms"], "avg_launch_ms": g["ms"] / max(g["launches"], 1),
                 "alg_tflops": tfl, "alg_flops_per_launch": g["flops"] / max(g["launches"], 1),
                 "alg_gbs": gbs, "alg_bytes_per_launch": g["bytes"] / max(g["launches"], 1),
@@ -345,14 +345,15 @@ def main():
             # measured HBM traffic of the generator launches from an earlier rocprofv3 --pmc pass of THIS build and
             # workload (profiles/traffic.json: keyed on generator mode, utterances and padded frames)
             traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(traffic_file) and not any(os.environ.get(k) for k in ("VSP_LIB_PATH", "VSP_GEN16", "VSP_FUSE_PAIRS", "VSP_CHUNK_MB")):
+            if os.path.exists(traffic_file) and not any(os.environ.get(k) for k in ("VSP_LIB_PATH", "VSP_FUSE_PAIRS", "VSP_CHUNK_MB", "VSP_CHAIN_CH",
+                                                                                     "VSP_CHAIN_WAVES", "VSP_PAIR_IMPL", "VSP_PAIR_WAVES")):
                 try:
                     tr = json.load(open(traffic_file))
                     if tr.get("generator") == gen_mode and tr.get("utterances") == B and tr.get("padded_frames", tf_global) == tf_global \
-                            and tr.get("kernels", "g16") == "g16":
+                            and tr.get("kernels") == "g16c" + os.environ.get("VSP_CHAIN", "1"):
                         roof["traffic"] = tr["hbm_bytes_per_launch"]
                         roof["traffic_source"] = "previous PMC pass: " + str(tr.get("source"))
-                        roof["hbm_measured_gbs"] = tr["hbm_bytes_per_launch"] * g["launches"] / (g["ms"] * 1e-3) / 1e9
+                        roof["hbm_measured_gbs"] = tr["hbm_bytes_per_launch"] * tr.get("launches_per_step", g["launches"]) / (g["ms"] * 1e-3) / 1e9
                 except Exception:
                     pass
             out["roofline"] = roof

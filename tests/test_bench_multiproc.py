@@ -31,7 +31,7 @@ def test_two_rank_bench_self_launches_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["utterances_per_gpu"] == 4 and d["config"]["parallelism"] == "shard2" and d["config"]["global_batch"] == 8
     assert "cpu_baseline" not in d                            # timed on rank 0 at N = 1 only
-    assert d["roofline"]["launches"] == 59 and d["roofline"]["attention"]["launches"] == 8
+    assert d["roofline"]["launches"] == 57 and d["roofline"]["attention"]["launches"] == 8
 
 
 def test_c4_global_batch_is_sharded_over_the_ranks():
