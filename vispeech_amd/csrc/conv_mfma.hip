@@ -20,6 +20,7 @@
 // models.py:119-133, 271-290, 526-529; frame_prior_network.py:50-55.
 #include "kernels.h"
 
+#include <cstdlib>
 #include <cstring>
 
 namespace vsp {
@@ -81,13 +82,43 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // The staged window is then kept as f16 PAIRS of adjacent input channels, P[ci/2][t] (hi image, lo
 // image; time contiguous, same bytes as the f32 window): a B fragment (8 consecutive ci of one time
 // column) is four conflict-free ds_read_b32, and staging stays a 16-byte ds_write per four columns.
-template <int MT, int NT, int WM, int WN, bool F16S>
+//
+// RING (F16S only): the weights no longer come from global memory into every wave's registers one tap ahead (a tap of
+// these small GEMMs is 12-24 MFMAs per wave: ~0.2 us of matrix work in front of a ~0.8 us L2 round trip, and the WN
+// waves of a row group each fetched the same bytes).  The block's (m-tiles, chunk, tap) slice -- MT*WM contiguous
+// 4 KiB fragment images -- is copied ONCE by LDS-DMA into a ring of NS slots, D = NS - 1 steps ahead of its use,
+// synchronised like gen16.hip: counted vmcnt (a wave waits for ITS pieces of the step), one raw s_barrier per step
+// (nothing drains the DMA queue), A fragments by ds_read_b128.
+// CONV_DIAG: timing-only ablation builds (results wrong): bit 0 no MFMA, 1 no window loads, 2 no epilogue memory traffic,
+// 3 no weight copies.  0 in the product build.
+#ifndef CONV_DIAG
+#define CONV_DIAG 0
+#endif
+#if CONV_DIAG & 1
+#define CONV_MFMA16(a, b, c) ([&]() { asm volatile("" ::"v"(a), "v"(b)); return c; }())
+#else
+#define CONV_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#endif
+#define CONV_RAW_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+template <int N>
+__device__ __forceinline__ void conv_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+constexpr int conv_ring_slots(int MT, int WM) { return MT * WM * 4096 <= 8192 ? 4 : 3; }
+
+template <int MT, int NT, int WM, int WN, bool F16S, bool RING = false>
 __global__ void __launch_bounds__(64 * WM * WN, F16S ? 2 : 1) conv1d_f32_mfma(ConvArgs a) {
+  static_assert(!RING || F16S, "the weight ring serves the split-f16 path");
   constexpr int BN = 32 * NT * WN;
   constexpr int LWP = BN + CONV_HALO;
   constexpr int NW = WM * WN;
   constexpr int KG = CONV_CK / 8;
-  extern __shared__ __attribute__((aligned(16))) float xs[];  // [CONV_CK][LWP]
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // [CONV_CK][LWP] (+ the weight ring)
+  constexpr int SB = MT * WM * 4096;                  // bytes of one step's weights (RING)
+  constexpr int NS = conv_ring_slots(MT, WM), DEPTH = NS - 1;
+  constexpr int PW = MT * WM * 4 / NW;                // 1 KiB pieces per wave and step
+  static_assert(!RING || (MT * WM * 4) % NW == 0, "pieces divide over the waves");
+  [[maybe_unused]] char* const ring = reinterpret_cast<char*>(xs) + (size_t)CONV_CK * LWP * sizeof(float);
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -140,7 +171,34 @@ __global__ void __launch_bounds__(64 * WM * WN, F16S ? 2 : 1) conv1d_f32_mfma(Co
       }
     }
   };
-  load_a(0, a_cur);
+  if constexpr (!RING) load_a(0, a_cur);
+  // RING: step `it` = (chunk, tap); piece p of a step = (m-tile p / 4 of the block, 1 KiB sub-image p % 4).  M-tiles past
+  // the last one re-read it (their accumulators are never stored), so every wave issues PW pieces per step.
+  [[maybe_unused]] auto ring_dma = [&](int step) {
+    char* dst = ring + (step % NS) * SB;
+    if constexpr ((CONV_DIAG & 8) != 0) return;
+#pragma unroll
+    for (int u = 0; u < PW; ++u) {
+      const int p = u * NW + wave;
+      int mtile = blockIdx.y * (WM * MT) + (p >> 2);
+      mtile = mtile < n_mtiles ? mtile : n_mtiles - 1;
+      const float4* src = wp4 + (((size_t)mtile * total_it + step) * KG + (p & 3)) * 64 + lane;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
+    }
+  };
+  [[maybe_unused]] auto ring_wait = [&](int step) {       // my pieces of `step` have landed: younger are the steps after it
+    const int younger = total_it - 1 - step < DEPTH - 1 ? total_it - 1 - step : DEPTH - 1;
+    if (younger <= 0) conv_vmcnt<0>();
+    else if (younger == 1) conv_vmcnt<PW>();
+    else conv_vmcnt<2 * PW>();
+  };
+  static_assert(DEPTH <= 3, "ring_wait covers up to two younger steps");
+  if constexpr (RING) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+      if (d < total_it) ring_dma(d);
+  }
 
   const float* xb = a.x + (size_t)b * a.x_bs;
   // vectorised staging needs 16-byte aligned rows (true for every internal [B][C][Ts] buffer)
@@ -164,8 +222,8 @@ __global__ void __launch_bounds__(64 * WM * WN, F16S ? 2 : 1) conv1d_f32_mfma(Co
         for (int j = 0; j < RWP; ++j) {
           const int ci = chunk * CONV_CK + 2 * (wave + j * NW);
           va[j] = vb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (tin && ci < a.Cin) va[j] = *reinterpret_cast<const float4*>(xb + (size_t)ci * a.x_cs + t4);
-          if (tin && ci + 1 < a.Cin) vb[j] = *reinterpret_cast<const float4*>(xb + (size_t)(ci + 1) * a.x_cs + t4);
+          if (tin && ci < a.Cin && !(CONV_DIAG & 2)) va[j] = *reinterpret_cast<const float4*>(xb + (size_t)ci * a.x_cs + t4);
+          if (tin && ci + 1 < a.Cin && !(CONV_DIAG & 2)) vb[j] = *reinterpret_cast<const float4*>(xb + (size_t)(ci + 1) * a.x_cs + t4);
         }
         if (q4 < LW4) {
           const int lim = a.in_mask ? (len < a.T_in ? len : a.T_in) : a.T_in;
@@ -252,9 +310,15 @@ __global__ void __launch_bounds__(64 * WM * WN, F16S ? 2 : 1) conv1d_f32_mfma(Co
         }
       }
     }
-    __syncthreads();
+    if constexpr (!RING) __syncthreads();
     for (int tap = 0; tap < a.K; ++tap, ++it) {
-      if (it + 1 < total_it) load_a(it + 1, a_nxt);
+      if constexpr (RING) {
+        ring_wait(it);
+        CONV_RAW_BARRIER();          // the step's weights (tap 0: and the window) are visible; step it - 1 is read out
+        if (it + DEPTH < total_it) ring_dma(it + DEPTH);
+      } else {
+        if (it + 1 < total_it) load_a(it + 1, a_nxt);
+      }
       if constexpr (F16S) {
         // column of this lane in the pair images, rows 8*ks + 4*h + i
         const int col = wn * (NT * 32) + l31 + off + tap * a.dil;
@@ -270,14 +334,21 @@ __global__ void __launch_bounds__(64 * WM * WN, F16S ? 2 : 1) conv1d_f32_mfma(Co
           }
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
-            const f16x8 ah = __builtin_bit_cast(f16x8, a_cur[mt][2 * ks]);
-            const f16x8 al = __builtin_bit_cast(f16x8, a_cur[mt][2 * ks + 1]);
+            f16x8 ah, al;
+            if constexpr (RING) {
+              const char* pa = ring + (it % NS) * SB + (wm * MT + mt) * 4096 + ks * 2048 + lane * 16;
+              ah = *reinterpret_cast<const f16x8*>(pa);
+              al = *reinterpret_cast<const f16x8*>(pa + 1024);
+            } else {
+              ah = __builtin_bit_cast(f16x8, a_cur[mt][2 * ks]);
+              al = __builtin_bit_cast(f16x8, a_cur[mt][2 * ks + 1]);
+            }
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[nt], acc[mt][nt], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = CONV_MFMA16(ah, bh[nt], acc[mt][nt]);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) crs[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[nt], crs[mt][nt], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt) crs[mt][nt] = CONV_MFMA16(ah, bl[nt], crs[mt][nt]);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) crs[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[nt], crs[mt][nt], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt) crs[mt][nt] = CONV_MFMA16(al, bh[nt], crs[mt][nt]);
           }
         }
       }
@@ -300,12 +371,15 @@ __global__ void __launch_bounds__(64 * WM * WN, F16S ? 2 : 1) conv1d_f32_mfma(Co
           }
         }
       }
+      if constexpr (!RING) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int kg = 0; kg < KG; ++kg) a_cur[mt][kg] = a_nxt[mt][kg];
+          for (int kg = 0; kg < KG; ++kg) a_cur[mt][kg] = a_nxt[mt][kg];
+      }
     }
-    __syncthreads();
+    if constexpr (RING) CONV_RAW_BARRIER();   // the window is read out
+    else __syncthreads();
   }
 
   if constexpr (F16S) {
@@ -316,10 +390,119 @@ __global__ void __launch_bounds__(64 * WM * WN, F16S ? 2 : 1) conv1d_f32_mfma(Co
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][nt][r] += crs[mt][nt][r] * (1.f / 2048.f);
   }
+  if constexpr ((CONV_DIAG & 4) != 0) {
+    float keep = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) keep += acc[mt][nt][0];
+    if (keep == 1.2345e-30f) a.out[0] = keep;
+    return;
+  }
   // ---- epilogue
   const float* resb = a.res ? a.res + (size_t)b * a.r_bs : nullptr;
   float* outb = a.out + (size_t)b * a.o_bs;
   const float* condb = a.cond ? a.cond + (size_t)b * a.cond_bs : nullptr;
+  if (a.ups_s == 0) {
+    // Plain (non-polyphase) store, the form every frame-rate convolution takes.  A lane owns 16 rows of a tile as four
+    // groups of four CONSECUTIVE rows (8 g + 4 h + 0..3): bias / conditioning come as one 16-byte load per group,
+    // addresses are 32-bit offsets into buffer descriptors, and every predicate (row < M, column < Nq, operand
+    // present) selects the out-of-range offset instead of a branch (loads give 0, stores are dropped).
+    constexpr int OOR = 0x7ffffff0;
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(outb, 0, OOR, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(resb ? resb : outb), 0, OOR, 0x00020000);
+    const bool gate_ep = a.act == 2;
+    auto row_vec = [&](const float* p, int row0, float (&v)[4]) {     // p[row0 .. row0 + 3], rows >= M read as 0
+      v[0] = v[1] = v[2] = v[3] = 0.f;
+      if (!p) return;
+      if (row0 + 3 < a.M && (reinterpret_cast<uintptr_t>(p + row0) & 15) == 0) {
+        const float4 t = *reinterpret_cast<const float4*>(p + row0);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (row0 + i < a.M) v[i] = p[row0 + i];
+      }
+    };
+    if (gate_ep) {
+      // WN gate (reference commons.py:100-107): tiles (2i, 2i+1) hold the tanh / sigmoid halves.
+      if constexpr (MT % 2 == 0) {
+#pragma unroll
+        for (int mp = 0; mp < MT / 2; ++mp) {
+          const int mtile = mtile0 + 2 * mp;
+          if (mtile + 1 >= n_mtiles) continue;
+          float ba[4][4], bb[4][4], ca[4][4], cb[4][4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            row_vec(a.bias, mtile * 32 + 8 * g + 4 * h, ba[g]);
+            row_vec(a.bias, mtile * 32 + 32 + 8 * g + 4 * h, bb[g]);
+            row_vec(condb, mtile * 32 + 8 * g + 4 * h, ca[g]);
+            row_vec(condb, mtile * 32 + 32 + 8 * g + 4 * h, cb[g]);
+          }
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int q = t0 + (wn * NT + nt) * 32 + l31;
+            const bool qin = q < a.Nq, valid = q < len;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int g = r >> 2, i = r & 3;
+              float va = acc[2 * mp][nt][r], vb = acc[2 * mp + 1][nt][r];
+              if (a.bias) { va += ba[g][i]; vb += bb[g][i]; }
+              if (condb) { va += ca[g][i]; vb += cb[g][i]; }
+              float v = tanhf(va) * (1.f / (1.f + expf(-vb)));
+              if (a.mask_post && !valid) v = 0.f;
+              const int orow = (mtile >> 1) * 32 + 8 * g + 4 * h + i;
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro, qin ? (orow * (int)a.o_cs + q) * 4 : OOR, 0, 0);
+            }
+          }
+        }
+      }
+      return;
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int mtile = mtile0 + mt;
+      if (mtile >= n_mtiles) continue;
+      float bv[4][4], cv[4][4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        row_vec(a.bias, mtile * 32 + 8 * g + 4 * h, bv[g]);
+        row_vec(condb, mtile * 32 + 8 * g + 4 * h, cv[g]);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int q = t0 + (wn * NT + nt) * 32 + l31;
+        const bool qin = q < a.Nq, valid = q < len;
+        // all loads of the tile first (res / out_prev may alias out), then the arithmetic and the stores
+        int oo[16];
+        unsigned rv[16], pv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = mtile * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+          const bool st = qin && row < a.M;
+          oo[r] = st ? (row * (int)a.o_cs + q) * 4 : OOR;
+          rv[r] = __builtin_amdgcn_raw_buffer_load_b32(rr, (st && resb) ? (row * (int)a.r_cs + q) * 4 : OOR, 0, 0);
+          pv[r] = __builtin_amdgcn_raw_buffer_load_b32(ro, a.acc_prev ? oo[r] : OOR, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int g = r >> 2, i = r & 3;
+          float v = acc[mt][nt][r];
+          if (a.bias) v += bv[g][i];
+          if (condb) v += cv[g][i];
+          if (a.act == 1) v = fmaxf(v, 0.f);
+          if (a.mask_pre && !valid) v = 0.f;
+          if (a.alpha != 1.f) v *= a.alpha;
+          if (resb) v += __uint_as_float(rv[r]);
+          if (a.acc_prev) v += __uint_as_float(pv[r]);
+          if (a.div != 1.f) v /= a.div;
+          if (a.mask_post && !valid) v = 0.f;
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro, oo[r], 0, 0);
+        }
+      }
+    }
+    return;
+  }
   if (a.act == 2) {
     // WN gate (reference commons.py:100-107): tiles (2i, 2i+1) hold the tanh / sigmoid halves.
     if constexpr (MT % 2 == 0) {
@@ -398,12 +581,14 @@ __global__ void __launch_bounds__(64 * WM * WN, F16S ? 2 : 1) conv1d_f32_mfma(Co
   }
 }
 
-template <int MT, int NT, int WM, int WN, bool F16S = false>
+template <int MT, int NT, int WM, int WN, bool F16S = false, bool RING = false>
 static hipError_t launch_tile(const ConvArgs& a, int B, hipStream_t s) {
   constexpr int BN = 32 * NT * WN, BM = 32 * MT * WM;
-  constexpr size_t lds = (size_t)CONV_CK * (BN + CONV_HALO) * sizeof(float);
+  constexpr size_t lds = (size_t)CONV_CK * (BN + CONV_HALO) * sizeof(float) +
+                         (RING ? (size_t)conv_ring_slots(MT, WM) * MT * WM * 4096 : 0);
+  static_assert(lds <= 160 * 1024, "LDS budget (<= 80 KiB: two blocks per CU)");
   static bool attr_set = false;
-  auto kern = conv1d_f32_mfma<MT, NT, WM, WN, F16S>;
+  auto kern = conv1d_f32_mfma<MT, NT, WM, WN, F16S, RING>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -418,6 +603,21 @@ static hipError_t launch_tile(const ConvArgs& a, int B, hipStream_t s) {
 hipError_t launch_conv(const ConvArgs& a, int B, hipStream_t s) {
   if ((a.K - 1) * a.dil + 3 > CONV_HALO || a.K < 1 || a.Nq <= 0 || B <= 0) return hipErrorInvalidValue;
   const bool gate = a.act == 2;
+  static int ring = -1;   // VSP_FRAME_RING=0: weights from global memory into registers (the round-1 form of these kernels)
+  if (ring < 0) { const char* e = getenv("VSP_FRAME_RING"); ring = e ? atoi(e) != 0 : 1; }
+  if (a.f16s && ring) {
+    if (a.ups_s > 0) return hipErrorInvalidValue;
+    if (a.M <= 32 && !gate) {
+      if (a.Nq >= 1024) return launch_tile<1, 4, 1, 4, true, true>(a, B, s);
+      return launch_tile<1, 1, 1, 2, true, true>(a, B, s);
+    }
+    if (a.Nq <= 96) return launch_tile<2, 1, 1, 2, true, true>(a, B, s);
+    if (a.M <= 64 || (a.M % 128 != 0 && a.M < 256)) {
+      if (a.Nq >= 1024) return launch_tile<2, 2, 1, 4, true, true>(a, B, s);
+      return launch_tile<2, 1, 1, 4, true, true>(a, B, s);
+    }
+    return launch_tile<2, 2, 2, 2, true, true>(a, B, s);
+  }
   if (a.f16s) {
     // split-f16 path: two accumulators per tile, so at most MT*NT = 4 tiles per wave
     if (a.ups_s > 0) return hipErrorInvalidValue;
