@@ -11,6 +11,6 @@ for i in $(seq 1 "$N"); do
     env $E python3 "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline 2> /dev/null | python3 -c "
 import json, sys
 d = json.loads(sys.stdin.read().strip().splitlines()[-1]); r = d['roofline']
-print('== [%s] #%s: %.2f ms/step  generator %.2f ms in %d launches  hbm-alg %.0f GB/s' % (sys.argv[1], sys.argv[2], d['ms_per_step'], r['kernel_ms_per_step'], r['launches'], r['alg_gbs']))" "$E" "$i"
+print('== [%s] #%s: %.2f ms/step  generator %.2f ms in %d launches  frame-rate convs %.2f ms  attention %.2f ms' % (sys.argv[1], sys.argv[2], d['ms_per_step'], r['kernel_ms_per_step'], r['launches'], r['frame_rate_convs']['ms_per_step'], r['attention']['ms_per_step']))" "$E" "$i"
   done
 done

@@ -187,11 +187,26 @@ __global__ void __launch_bounds__(64 * WM * WN, F16S ? 2 : 1) conv1d_f32_mfma(Co
                                        (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
     }
   };
-  [[maybe_unused]] auto ring_wait = [&](int step) {       // my pieces of `step` have landed: younger are the steps after it
+  // PREF (RING tiles of <= 128 columns, one staging sweep): the next chunk's window is requested right behind the
+  // weight copy of the chunk's first step and converted / written after the chunk's last tap -- its HBM / L2 round trip
+  // runs in the shadow of the chunk's matrix work.  The loads are younger than the weight copies of the next DEPTH
+  // steps: the counted waits of those steps leave them in flight.
+  constexpr bool PREF = RING && ((BN + CONV_HALO + 3) >> 2) <= 64;
+  constexpr int RWPF = PREF ? (CONV_CK / 2) / NW : 1;
+  constexpr int NPF = 2 * RWPF;                        // window loads per wave and chunk
+  [[maybe_unused]] int pf_step = -1000;                // step at which the outstanding window request was issued
+  [[maybe_unused]] auto ring_wait = [&](int step) {   // my pieces of `step` have landed: younger are the steps after it
     const int younger = total_it - 1 - step < DEPTH - 1 ? total_it - 1 - step : DEPTH - 1;
-    if (younger <= 0) conv_vmcnt<0>();
-    else if (younger == 1) conv_vmcnt<PW>();
-    else conv_vmcnt<2 * PW>();
+    const bool pf = PREF && step > pf_step && step - pf_step <= DEPTH;
+    if (pf) {
+      if (younger <= 0) conv_vmcnt<NPF>();
+      else if (younger == 1) conv_vmcnt<PW + NPF>();
+      else conv_vmcnt<2 * PW + NPF>();
+    } else {
+      if (younger <= 0) conv_vmcnt<0>();
+      else if (younger == 1) conv_vmcnt<PW>();
+      else conv_vmcnt<2 * PW>();
+    }
   };
   static_assert(DEPTH <= 3, "ring_wait covers up to two younger steps");
   if constexpr (RING) {
@@ -207,10 +222,50 @@ __global__ void __launch_bounds__(64 * WM * WN, F16S ? 2 : 1) conv1d_f32_mfma(Co
   const int off = (t0 - a.pad) - t_start;
   const int LW4 = (LW + off + 3) >> 2;
   const float* xsb = xs + h * LWP + wn * (NT * 32) + l31 + off;
+  [[maybe_unused]] float4 pva[RWPF], pvb[RWPF];
+  [[maybe_unused]] auto st_load = [&](int chunk) {
+    const int t4 = t_start + 4 * lane;
+    const bool tin = lane < LW4 && t4 >= 0 && t4 < a.T_in;
+#pragma unroll
+    for (int j = 0; j < RWPF; ++j) {
+      const int ci = chunk * CONV_CK + 2 * (wave + j * NW);
+      // (always two loads per pair, so that the counted waits know how many are in flight: absent ones re-read row 0)
+      const float* pa = xb + (size_t)(tin && ci < a.Cin ? ci : 0) * a.x_cs + (tin ? t4 : 0);
+      const float* pb = xb + (size_t)(tin && ci + 1 < a.Cin ? ci + 1 : 0) * a.x_cs + (tin ? t4 : 0);
+      pva[j] = *reinterpret_cast<const float4*>(pa);
+      pvb[j] = *reinterpret_cast<const float4*>(pb);
+    }
+  };
+  [[maybe_unused]] auto st_write = [&](int chunk) {
+    if (lane >= LW4) return;
+    const int t4 = t_start + 4 * lane;
+    const bool tin = t4 >= 0 && t4 < a.T_in;
+    const int lim = a.in_mask ? (len < a.T_in ? len : a.T_in) : a.T_in;
+#pragma unroll
+    for (int j = 0; j < RWPF; ++j) {
+      const int ci = chunk * CONV_CK + 2 * (wave + j * NW);
+      const bool ina = tin && ci < a.Cin, inb = tin && ci + 1 < a.Cin;
+      float ea[4] = {pva[j].x, pva[j].y, pva[j].z, pva[j].w}, eb[4] = {pvb[j].x, pvb[j].y, pvb[j].z, pvb[j].w};
+      unsigned wh4[4], wl4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float x0 = (ina && t4 + u < lim) ? ea[u] : 0.f, x1 = (inb && t4 + u < lim) ? eb[u] : 0.f;
+        if (a.in_act) { x0 = x0 > 0.f ? x0 : x0 * a.in_slope; x1 = x1 > 0.f ? x1 : x1 * a.in_slope; }
+        split_pair(x0, x1, wh4[u], wl4[u]);
+      }
+      const int o = (wave + j * NW) * LWP + 4 * lane;
+      *reinterpret_cast<u32x4*>(ph + o) = u32x4{wh4[0], wh4[1], wh4[2], wh4[3]};
+      *reinterpret_cast<u32x4*>(pl + o) = u32x4{wl4[0], wl4[1], wl4[2], wl4[3]};
+    }
+  };
+  const bool pref = PREF && vec && (CONV_DIAG & 2) == 0;
+  if constexpr (PREF) { if (pref) st_load(0); }
   int it = 0;
   for (int chunk = 0; chunk < a.nchunks; ++chunk) {
     // ---- stage x[chunk] -> LDS with the prologue applied
-    if (vec && F16S) {
+    if (pref) {
+      if constexpr (PREF) st_write(chunk);      // (the compiler waits for the window here: a chunk after its request)
+    } else if (vec && F16S) {
       // pairs of adjacent input channels: two 16-byte loads -> one 16-byte LDS store per image
       constexpr int RWP = (CONV_CK / 2) / NW;
       for (int q0 = 0; q0 < LW4; q0 += 64) {
@@ -316,6 +371,9 @@ __global__ void __launch_bounds__(64 * WM * WN, F16S ? 2 : 1) conv1d_f32_mfma(Co
         ring_wait(it);
         CONV_RAW_BARRIER();          // the step's weights (tap 0: and the window) are visible; step it - 1 is read out
         if (it + DEPTH < total_it) ring_dma(it + DEPTH);
+        if constexpr (PREF) {
+          if (pref && tap == 0 && chunk + 1 < a.nchunks) { st_load(chunk + 1); pf_step = it; }
+        }
       } else {
         if (it + 1 < total_it) load_a(it + 1, a_nxt);
       }
