@@ -236,29 +236,45 @@ __global__ void __launch_bounds__(64 * WM * WN, F16S ? 2 : 1) conv1d_f32_mfma(Co
       pvb[j] = *reinterpret_cast<const float4*>(pb);
     }
   };
+  // conversion of a staged pair of channels x four times: leaky-relu as max(x, slope x) (0 <= slope <= 1; slope 1 =
+  // none), packed f32 arithmetic, the rounded hi pinned before the residual is taken (gen16.hip: g16_split4)
+  typedef float f32x2v __attribute__((ext_vector_type(2)));
+  [[maybe_unused]] const float slope_eff = a.in_act ? a.in_slope : 1.f;
   [[maybe_unused]] auto st_write = [&](int chunk) {
     if (lane >= LW4) return;
     const int t4 = t_start + 4 * lane;
     const bool tin = t4 >= 0 && t4 < a.T_in;
     const int lim = a.in_mask ? (len < a.T_in ? len : a.T_in) : a.T_in;
+    const bool tfull = tin && t4 + 3 < lim;
 #pragma unroll
     for (int j = 0; j < RWPF; ++j) {
       const int ci = chunk * CONV_CK + 2 * (wave + j * NW);
       const bool ina = tin && ci < a.Cin, inb = tin && ci + 1 < a.Cin;
-      float ea[4] = {pva[j].x, pva[j].y, pva[j].z, pva[j].w}, eb[4] = {pvb[j].x, pvb[j].y, pvb[j].z, pvb[j].w};
+      const float ea[4] = {pva[j].x, pva[j].y, pva[j].z, pva[j].w}, eb[4] = {pvb[j].x, pvb[j].y, pvb[j].z, pvb[j].w};
       unsigned wh4[4], wl4[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        float x0 = (ina && t4 + u < lim) ? ea[u] : 0.f, x1 = (inb && t4 + u < lim) ? eb[u] : 0.f;
-        if (a.in_act) { x0 = x0 > 0.f ? x0 : x0 * a.in_slope; x1 = x1 > 0.f ? x1 : x1 * a.in_slope; }
-        split_pair(x0, x1, wh4[u], wl4[u]);
+        f32x2v x = {ea[u], eb[u]};
+        if (!(tfull && inb)) {                          // window edge / ragged channel count: zero what is not there
+          x.x = (ina && t4 + u < lim) ? x.x : 0.f;
+          x.y = (inb && t4 + u < lim) ? x.y : 0.f;
+        }
+        const f32x2v y = x * slope_eff;
+        asm("v_max_f32 %0, %1, %2" : "=v"(x.x) : "v"(x.x), "v"(y.x));
+        asm("v_max_f32 %0, %1, %2" : "=v"(x.y) : "v"(x.y), "v"(y.y));
+        f16x2 hi = __builtin_convertvector(x, f16x2);
+        asm volatile("" : "+v"(hi));
+        const f32x2v back = __builtin_convertvector(hi, f32x2v);
+        const f16x2 lo = __builtin_convertvector((x - back) * 2048.f, f16x2);
+        wh4[u] = __builtin_bit_cast(unsigned, hi);
+        wl4[u] = __builtin_bit_cast(unsigned, lo);
       }
       const int o = (wave + j * NW) * LWP + 4 * lane;
       *reinterpret_cast<u32x4*>(ph + o) = u32x4{wh4[0], wh4[1], wh4[2], wh4[3]};
       *reinterpret_cast<u32x4*>(pl + o) = u32x4{wl4[0], wl4[1], wl4[2], wl4[3]};
     }
   };
-  const bool pref = PREF && vec && (CONV_DIAG & 2) == 0;
+  const bool pref = PREF && vec && (CONV_DIAG & 2) == 0 && slope_eff >= 0.f && slope_eff <= 1.f;
   if constexpr (PREF) { if (pref) st_load(0); }
   int it = 0;
   for (int chunk = 0; chunk < a.nchunks; ++chunk) {
