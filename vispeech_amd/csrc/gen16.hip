@@ -501,9 +501,21 @@ hipError_t launch_g16_conv(const ClConvArgs& a, int B, hipStream_t s) {
     if (rows % 32 == 0) return launch_g16_tile<2, 2, 1, 8, 1>(a, B, s);
     return hipErrorInvalidValue;
   }
-  if (rows % 128 == 0) return launch_g16_tile<4, 4, 2, 4, 3>(a, B, s);   // 128 rows x 256 columns, one block per CU
-  if (rows % 64 == 0) return launch_g16_tile<4, 2, 1, 8, 3>(a, B, s);    //  64 rows x 256 columns, two blocks per CU
-  if (rows % 32 == 0) return launch_g16_tile<2, 2, 1, 8, 3>(a, B, s);    //  32 rows x 256 columns
+  // Row tile: 128 rows x 256 columns (one block per CU) when that fills the chip; a launch with fewer blocks than CUs
+  // (one or two utterances: the 256 / 128-channel stages) takes the 64- or 32-row tile and spreads over 2-4x the CUs.
+  // VSP_G16_ROWS=128|64|32 forces one.
+  static int force = -1, fill = 200;
+  if (force < 0) {
+    const char* e = getenv("VSP_G16_ROWS"); force = e ? atoi(e) : 0;
+    if (const char* f = getenv("VSP_G16_FILL")) fill = atoi(f);
+  }
+  const long col_tiles = (long)((a.Nq + 255) / 256) * B;
+  int want = 128;
+  if (force) want = force;
+  else if (col_tiles * (rows / 128 > 0 ? rows / 128 : 1) < fill) want = col_tiles * (rows / 64 > 0 ? rows / 64 : 1) < fill ? 32 : 64;
+  if (rows % 128 == 0 && want >= 128) return launch_g16_tile<4, 4, 2, 4, 3>(a, B, s);   // 128 rows x 256 columns, one block per CU
+  if (rows % 64 == 0 && want >= 64) return launch_g16_tile<4, 2, 1, 8, 3>(a, B, s);     //  64 rows x 256 columns
+  if (rows % 32 == 0) return launch_g16_tile<2, 2, 1, 8, 3>(a, B, s);                   //  32 rows x 256 columns
   return hipErrorInvalidValue;
 }
 
