@@ -283,10 +283,12 @@ int plan_model(vsp_ctx* ctx) {
     Q.proj_s = p.conv(inter, h, 1, 1, 0, true);
   }
   // generator (its channel-major f32 form is the second implementation kept for VSP_GENERATOR=f32)
-  p.f16s = false;
+  // (conv_pre and the speaker conditioning run on the split-f16 path whenever the vocoder does)
+  p.f16s = ctx->frame_f16s && ctx->gen_mode != 0;
   const int c0 = c.upsample_initial_channel;
   m.g_pre = p.conv(c0, inter, 7, 1, 3, true);
   m.g_cond = p.conv(c0, gin, 1, 1, 0, true);
+  p.f16s = false;
   int ch = c0;
   // the split-f16 channels-last generator covers channel counts of 32 or multiples of 64
   m.has_cl = true;
