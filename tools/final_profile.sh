@@ -18,6 +18,7 @@ python3 "$R/bench.py" --workload C5 --steps 10 --no-cpu-baseline > "$O/bench_c5.
 python3 "$R/bench.py" --controls duration --steps 10 --cpu-sample 4 > "$O/bench_controls_duration.json" 2>> "$O/bench.err"
 python3 "$R/bench.py" --controls none --steps 5 --cpu-sample 2 > "$O/bench_controls_none.json" 2>> "$O/bench.err"
 VSP_GENERATOR=f16 python3 "$R/bench.py" --cpu-sample 2 > "$O/bench_f16mode.json" 2>> "$O/bench.err"
+python3 "$R/bench.py" --workload C2 --batch 1 --steps 50 --warmup 10 --no-cpu-baseline > "$O/bench_one_utterance.json" 2>> "$O/bench.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace" -o t -- python3 "$R/bench.py" --steps 4 --warmup 1 --profile-steps 0 --no-cpu-baseline > "$O/bench_traced.json" 2>> "$O/bench.err" || true
 python3 "$R/tools/trace_fused.py" "$O/trace/t_kernel_trace.csv" > "$O/generator_per_launch.txt" || true
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace_c5" -o t -- python3 "$R/bench.py" --workload C5 --steps 4 --warmup 1 --profile-steps 0 --no-cpu-baseline > "$O/bench_c5_traced.json" 2>> "$O/bench.err" || true
