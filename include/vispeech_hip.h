@@ -245,6 +245,19 @@ int vsp_has_voice_conversion(const vsp_ctx* ctx);
 int vsp_rq_spline(void* stream, int64_t n, int nb, const float* x, const float* uw, const float* uh,
                   const float* ud, int inverse, float tail_bound, float* y, float* logabsdet);
 
+/* ---- mel spectrogram (reference mel_processing.py:73-112) --------------------------------- */
+/* The mel basis the reference takes from librosa.filters.mel(sampling_rate, n_fft, n_mels, fmin, fmax) with that
+ * function's defaults (Slaney mel scale: linear below 1 kHz, logarithmic above; triangles between successive mel
+ * points; Slaney area normalisation): basis_host[n_mels][n_fft / 2 + 1], computed on the host in double precision.
+ * librosa is a third-party dependency of the reference (requirements.txt, no version pinned) and is not vendored:
+ * this restates its published algorithm.  fmax <= 0 means sampling_rate / 2. */
+int vsp_mel_filterbank(int sampling_rate, int n_fft, int n_mels, float fmin, float fmax, float* basis_host);
+/* spec_to_mel_torch (reference mel_processing.py:73-82): mel = log(clamp(basis @ spec, min = 1e-5)).
+ * spec [B][n_fft / 2 + 1][T] and mel [B][n_mels][T] are device pointers; the basis is built and uploaded inside the
+ * call.  vsp_spectrogram followed by this call = mel_spectrogram_torch (mel_processing.py:85-112). */
+int vsp_spec_to_mel(void* stream, int B, int T, int n_fft, int n_mels, int sampling_rate, float fmin, float fmax,
+                    const float* spec, float* mel);
+
 /* ---- vocoder operators, stand-alone (no context) ------------------------------------------ */
 /* The channels-last split-f16 convolution kernels of the generator as plain operators, for unit parity
  * and for callers that hold their own weights.  Activations are device pointers, fp32, channels-last

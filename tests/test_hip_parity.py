@@ -383,9 +383,9 @@ def test_reduced_precision_mode_is_opt_in_and_gated(dims, weights, golden_dir, m
     ref = g["o"].astype(np.float64)
     snr = 10 * np.log10((ref ** 2).sum() / ((o - ref) ** 2).sum())
     e = rel_err(o, ref)
-    # audio-domain metric of the reference's training loss (mel-L1 on log-mel, mel_processing.py:85-112)
-    from oracle.vispeech_oracle import mel_spectrogram
-    mel = lambda w: mel_spectrogram(w[:, 0].astype(np.float32), 44100, 2048, 512, 80).numpy()
+    # audio-domain metric of the reference's training loss (mel-L1 on log-mel, mel_processing.py:85-112, train.py:
+    # 163-177), computed on the GPU (vsp_spectrogram + vsp_spec_to_mel)
+    mel = lambda w: to_np(m._engine.mel_spectrogram(w[:, 0].astype(np.float32), 80, 44100)).astype(np.float64)
     mel_l1 = float(np.abs(mel(o) - mel(ref)).mean())
     print(f"f16 generator: SNR {snr:.1f} dB, max rel err {e:.2e}, log-mel L1 {mel_l1:.2e}")
     assert snr >= 30.0

@@ -88,6 +88,8 @@ SIGNATURES = {
     "vsp_spectrogram_workspace_bytes": (_I64, [_P, _I, _I, _I]),
     "vsp_spectrogram": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _I64]),
     "vsp_rq_spline": (_I, [_P, _I64, _I, _P, _P, _P, _P, _I, _F, _P, _P]),
+    "vsp_mel_filterbank": (_I, [_I, _I, _I, _F, _F, _P]),
+    "vsp_spec_to_mel": (_I, [_P, _I, _I, _I, _I, _I, _F, _F, _P, _P]),
     "vsp_cl_conv1d": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _F, _P, _I, _P]),
     "vsp_cl_resblock": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P]),
     "vsp_profile_enable": (_I, [_P, _I]),

@@ -1380,6 +1380,72 @@ int vsp_rq_spline(void* stream, int64_t n, int nb, const float* x, const float* 
   return e == hipSuccess ? VSP_OK : (e == hipErrorInvalidValue ? VSP_ERR_UNSUPPORTED : VSP_ERR_HIP);
 }
 
+// -------------------------------------------------------------------------------------------- mel spectrogram
+namespace {
+// librosa.filters.mel with its defaults (htk = False, norm = 'slaney'), in double precision
+bool mel_basis(int sr, int n_fft, int n_mels, double fmin, double fmax, std::vector<float>& w) {
+  if (sr <= 0 || n_fft < 2 || (n_fft & 1) || n_mels < 1) return false;
+  if (fmax <= 0.0) fmax = sr / 2.0;
+  if (fmin < 0.0 || fmax <= fmin) return false;
+  const int nf = n_fft / 2 + 1;
+  const double f_sp = 200.0 / 3.0, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = std::log(6.4) / 27.0;
+  auto hz_to_mel = [&](double f) { return f >= min_log_hz ? min_log_mel + std::log(f / min_log_hz) / logstep : f / f_sp; };
+  auto mel_to_hz = [&](double m) { return m >= min_log_mel ? min_log_hz * std::exp(logstep * (m - min_log_mel)) : f_sp * m; };
+  std::vector<double> mel_f(n_mels + 2);
+  const double m0 = hz_to_mel(fmin), m1 = hz_to_mel(fmax);
+  for (int i = 0; i < n_mels + 2; ++i) mel_f[i] = mel_to_hz(m0 + (m1 - m0) * i / (n_mels + 1));
+  w.assign((size_t)n_mels * nf, 0.f);
+  for (int m = 0; m < n_mels; ++m) {
+    const double enorm = 2.0 / (mel_f[m + 2] - mel_f[m]);
+    for (int k = 0; k < nf; ++k) {
+      const double f = (sr / 2.0) * k / (nf - 1);
+      const double lower = (f - mel_f[m]) / (mel_f[m + 1] - mel_f[m]), upper = (mel_f[m + 2] - f) / (mel_f[m + 2] - mel_f[m + 1]);
+      const double v = std::max(0.0, std::min(lower, upper));
+      w[(size_t)m * nf + k] = (float)(v * enorm);
+    }
+  }
+  return true;
+}
+}  // namespace
+
+int vsp_mel_filterbank(int sampling_rate, int n_fft, int n_mels, float fmin, float fmax, float* basis_host) {
+  if (!basis_host) return VSP_ERR_ARG;
+  std::vector<float> w;
+  if (!mel_basis(sampling_rate, n_fft, n_mels, fmin, fmax, w)) return VSP_ERR_ARG;
+  std::memcpy(basis_host, w.data(), w.size() * sizeof(float));
+  return VSP_OK;
+}
+
+int vsp_spec_to_mel(void* stream, int B, int T, int n_fft, int n_mels, int sampling_rate, float fmin, float fmax,
+                    const float* spec, float* mel) {
+  if (!spec || !mel || B < 0 || T < 0) return VSP_ERR_ARG;
+  std::vector<float> w;
+  if (!mel_basis(sampling_rate, n_fft, n_mels, fmin, fmax, w)) return VSP_ERR_ARG;
+  if (B == 0 || T == 0) return VSP_OK;
+  const int nf = n_fft / 2 + 1;
+  std::vector<int> lo(n_mels), hi(n_mels);
+  for (int m = 0; m < n_mels; ++m) {
+    int a = nf, b = 0;
+    for (int k = 0; k < nf; ++k)
+      if (w[(size_t)m * nf + k] != 0.f) { a = std::min(a, k); b = k + 1; }
+    lo[m] = a < b ? a : 0; hi[m] = a < b ? b : 0;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  void *dw = nullptr, *dr = nullptr;
+  hipError_t e = hipMalloc(&dw, w.size() * 4);
+  if (e == hipSuccess) e = hipMalloc(&dr, (size_t)2 * n_mels * 4);
+  if (e == hipSuccess) e = hipMemcpyAsync(dw, w.data(), w.size() * 4, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(dr, lo.data(), (size_t)n_mels * 4, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(static_cast<int*>(dr) + n_mels, hi.data(), (size_t)n_mels * 4, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess)
+    e = launch_spec_to_mel(spec, static_cast<const float*>(dw), static_cast<const int*>(dr), static_cast<const int*>(dr) + n_mels,
+                           mel, B, nf, n_mels, T, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);      // (the host vectors and the scratch die with this frame)
+  if (dw) (void)hipFree(dw);
+  if (dr) (void)hipFree(dr);
+  return e == hipSuccess ? VSP_OK : VSP_ERR_HIP;
+}
+
 // -------------------------------------------------------------------------------------------- stand-alone vocoder operators
 namespace {
 struct DevBuf {           // hipMalloc'd scratch of one stand-alone call

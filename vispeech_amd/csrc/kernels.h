@@ -96,6 +96,9 @@ bool g16_pair_supported(int C, int K, int dil);
 hipError_t launch_g16_pair(const ClPairArgs& a, int B, hipStream_t s);
 size_t packed_g16_halfs(int rows, int Cin, int K);
 void pack_g16_weights(uint16_t* dst, int rows, int Cin, int K, const float* dense /* [rows][Cin][K] */);
+// mel[b][m][t] = log(max(sum_{f in [lo[m], hi[m])} basis[m][f] * spec[b][f][t], 1e-5))  (reference mel_processing.py:16-22, 73-82)
+hipError_t launch_spec_to_mel(const float* spec, const float* basis, const int* lo, const int* hi, float* mel, int B,
+                              int n_freq, int n_mels, int T, hipStream_t s);
 hipError_t launch_transpose_ct(const float* x, long x_bs, long x_cs, float* y, long y_bs, int y_ts, int B, int C,
                                int T, hipStream_t s);
 hipError_t launch_conv_post_cl(const float* x, long x_bs, int x_ts, const float* w, int C, int K, float slope,

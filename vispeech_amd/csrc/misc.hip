@@ -557,4 +557,24 @@ hipError_t launch_stft_magnitude(const float* ri, long r_bs, long r_cs, float* s
   return hipGetLastError();
 }
 
+// mel projection + dynamic range compression (reference mel_processing.py:16-22, 73-82).  A mel filter is a triangle
+// over a short run of bins: only [lo, hi) is visited, in increasing bin order.
+__global__ void spec_to_mel_kernel(const float* __restrict__ spec, const float* __restrict__ basis,
+                                   const int* __restrict__ lo, const int* __restrict__ hi, float* __restrict__ mel,
+                                   int n_freq, int n_mels, int T) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y, b = blockIdx.z;
+  if (t >= T) return;
+  const float* sp = spec + (size_t)b * n_freq * T + t;
+  const float* w = basis + (size_t)m * n_freq;
+  float acc = 0.f;
+  for (int f = lo[m]; f < hi[m]; ++f) acc = fmaf(w[f], sp[(size_t)f * T], acc);
+  mel[((size_t)b * n_mels + m) * T + t] = logf(fmaxf(acc, 1e-5f));
+}
+hipError_t launch_spec_to_mel(const float* spec, const float* basis, const int* lo, const int* hi, float* mel, int B,
+                              int n_freq, int n_mels, int T, hipStream_t s) {
+  hipLaunchKernelGGL(spec_to_mel_kernel, dim3((T + 255) / 256, n_mels, B), dim3(256), 0, s, spec, basis, lo, hi, mel,
+                     n_freq, n_mels, T);
+  return hipGetLastError();
+}
+
 }  // namespace vsp

@@ -318,6 +318,26 @@ class Engine:
         _lib.check(rc, self.ctx, "vsp_spectrogram")
         return spec
 
+    def spec_to_mel(self, spec, n_mels: int, sampling_rate: int, fmin: float = 0.0, fmax: Optional[float] = None) -> torch.Tensor:
+        """``mel_processing.spec_to_mel_torch`` (reference mel_processing.py:73-82): linear magnitude spectrogram
+        [B, n_fft // 2 + 1, T] -> log-mel [B, n_mels, T] (Slaney basis as ``librosa.filters.mel``, log(clamp(x, 1e-5)))."""
+        sp = _dev_f32(spec, self.device)
+        if sp.dim() != 3 or sp.shape[1] < 2:
+            raise ValueError("spec must be [B, n_fft // 2 + 1, T]")
+        B, nf, T = sp.shape
+        mel = self._f(B, int(n_mels), T)
+        with torch.cuda.device(self.device):
+            rc = self.lib.vsp_spec_to_mel(self._stream(), B, T, 2 * (nf - 1), int(n_mels), int(sampling_rate), float(fmin),
+                                          0.0 if fmax is None else float(fmax), _ptr(sp), _ptr(mel))
+        _lib.check(rc, self.ctx, "vsp_spec_to_mel")
+        return mel
+
+    def mel_spectrogram(self, audio, n_mels: int, sampling_rate: int, fmin: float = 0.0, fmax: Optional[float] = None,
+                        hop_length: Optional[int] = None) -> torch.Tensor:
+        """``mel_processing.mel_spectrogram_torch`` (reference mel_processing.py:85-112) on the GPU: spectrogram, then
+        the mel projection and dynamic range compression."""
+        return self.spec_to_mel(self.spectrogram(audio, hop_length), n_mels, sampling_rate, fmin, fmax)
+
     def posterior_encoder(self, y, y_lengths, g, noise):
         """PosteriorEncoder.forward (reference models.py:233-241) -> (z, m, logs)."""
         y = _dev_f32(y, self.device)
