@@ -104,7 +104,7 @@ template <int N>
 __device__ __forceinline__ void conv_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-constexpr int conv_ring_slots(int MT, int WM) { return MT * WM * 4096 <= 8192 ? 4 : 3; }
+constexpr int conv_ring_slots(int MT, int WM) { return 3; }   // (four slots for the 8 KiB steps measured slower: 57 KiB per block = two blocks per CU instead of three)
 
 template <int MT, int NT, int WM, int WN, bool F16S, bool RING = false>
 __global__ void __launch_bounds__(64 * WM * WN, F16S ? 2 : 1) conv1d_f32_mfma(ConvArgs a) {
