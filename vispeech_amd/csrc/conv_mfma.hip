@@ -686,7 +686,13 @@ hipError_t launch_conv(const ConvArgs& a, int B, hipStream_t s) {
       return launch_tile<1, 1, 1, 2, true, true>(a, B, s);
     }
     if (a.Nq <= 96) return launch_tile<2, 1, 1, 2, true, true>(a, B, s);
-    if (a.M <= 64 || (a.M % 128 != 0 && a.M < 256)) {
+    // M % 128 == 0: 128-row x 128-column tiles (two blocks per CU) for long time axes; utterance-sized ones take the
+    // 64-row tile -- twice the blocks at three per CU fill the chip's rounds better than the halved window reuse
+    // costs (C3 -0.15 ms, one utterance -11 %; the 5168-frame utterance +4 % if it did).  VSP_FRAME_TILE=128|64 forces one.
+    static int force_rows = -1;
+    if (force_rows < 0) { const char* e = getenv("VSP_FRAME_TILE"); force_rows = e ? atoi(e) : 0; }
+    const bool wide = force_rows ? force_rows == 128 : a.Nq >= 1024;
+    if (a.M <= 64 || (a.M % 128 != 0 && a.M < 256) || !wide) {
       if (a.Nq >= 1024) return launch_tile<2, 2, 1, 4, true, true>(a, B, s);
       return launch_tile<2, 1, 1, 4, true, true>(a, B, s);
     }
