@@ -346,7 +346,7 @@ def main():
             # workload (profiles/traffic.json: keyed on generator mode, utterances and padded frames)
             traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(traffic_file) and not any(os.environ.get(k) for k in ("VSP_LIB_PATH", "VSP_FUSE_PAIRS", "VSP_CHUNK_MB", "VSP_CHAIN_CH",
-                                                                                     "VSP_CHAIN_WAVES", "VSP_PAIR_IMPL", "VSP_PAIR_WAVES")):
+                                                                                     "VSP_CHAIN_WAVES", "VSP_PAIR_WAVES", "VSP_G16_ROWS")):
                 try:
                     tr = json.load(open(traffic_file))
                     if tr.get("generator") == gen_mode and tr.get("utterances") == B and tr.get("padded_frames", tf_global) == tf_global \

@@ -174,15 +174,6 @@ struct Run {
     a.acc_prev = acc_prev ? 1 : 0; a.div = div;
     a.terms = ctx->gen_mode == 2 ? 1 : 3;
     const bool prof = prof_begin(VSP_PROF_GENERATOR);
-    if (ctx->pair_via_chain) {                         // experiment: the pair as a one-pair chain (g16_chain's pipelined main loop)
-      ClChainArgs c;
-      std::memset(&c, 0, sizeof c);
-      c.x = x; c.x_bs = bs; c.out = out; c.o_bs = bs;
-      c.w[0] = a.w1h; c.w[1] = a.w2h; c.b[0] = a.b1; c.b[1] = a.b2;
-      c.dil[0] = a.dil; c.np = 1; c.C = a.C; c.K = a.K; c.T = T; c.slope = a.slope;
-      c.acc_prev = a.acc_prev; c.div = a.div; c.terms = a.terms;
-      chk(launch_g16_chain(c, B, s), "g16_chain");
-    } else
     chk(launch_g16_pair(a, B, s), "g16_pair");
     if (prof) {
       // the two convolutions this launch replaces: SURVEY.md 8d charges each its input and its output (4 passes of
@@ -561,7 +552,6 @@ int vsp_create(const vsp_config* cfg, int device, vsp_ctx** out) {
   if (const char* e = getenv("VSP_CHUNK_MB")) ctx->chunk_mb = atof(e);
   if (const char* e = getenv("VSP_FUSE_PAIRS")) ctx->fuse_pairs = atoi(e) != 0;
   if (const char* e = getenv("VSP_CHAIN")) ctx->chain_mask = atoi(e);
-  if (const char* e = getenv("VSP_PAIR_IMPL")) ctx->pair_via_chain = std::strcmp(e, "chain") == 0;
   if (const char* e = getenv("VSP_CHAIN_CH")) ctx->chain_ch = atoi(e);
   *out = ctx;  // returned even on failure so that vsp_last_error can be read; caller destroys it
   return rc;

@@ -122,7 +122,6 @@ struct vsp_ctx {
   int att_ksplit = -1;     // attention key-split blocks: -1 automatic (under-filled grids), 0 never, 1 always (VSP_ATT_KSPLIT)
   int chain_mask = 0x1;    // ResBlock chains (all dilation pairs of a ResBlock in one launch): bit 0 = k3, 1 = k7, 2 = k11 (VSP_CHAIN=<mask>; measured: only k3 pays)
   int chain_ch = 32;       // widest stage that runs chains (VSP_CHAIN_CH)
-  bool pair_via_chain = false;   // VSP_PAIR_IMPL=chain: conv pairs as one-pair g16_chain launches
   bool fuse_pairs = true;  // ResBlock conv pairs of the 32/64-channel stages as one launch (VSP_FUSE_PAIRS=0: two launches)
   double chunk_mb = 0.0;   // generator batch chunk in MiB per activation tensor (VSP_CHUNK_MB; 0 = whole batch: measured faster)
   // profiling: HIP event pairs around the launches of a class (VSP_PROF_* in vispeech_hip.h)
