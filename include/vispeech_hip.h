@@ -273,6 +273,17 @@ int vsp_spec_to_mel(void* stream, int B, int T, int n_fft, int n_mels, int sampl
 int vsp_cl_conv1d(void* stream, int B, int T, int Cin, int Cout, int K, int dilation, const float* x,
                   const float* w_host, const float* bias_host, float in_slope, const float* res, int terms,
                   float* out);
+/* vsp_conv1d: the frame- / phoneme-rate convolution kernel (conv1d_f32_mfma) as a plain operator on the reference's
+ * layout, x [B][Cin][T] -> out [B][Cout][T] (device, fp32, T contiguous):
+ *   out = epilogue(conv1d(prologue(x), w, dilation, padding = dilation (K - 1) / 2) + bias)
+ * prologue: x * mask (lengths != NULL and mask_in) then leaky_relu(x, in_slope) when in_act; epilogue: act 0 none,
+ * 1 relu, 2 WN gate tanh(rows [0, Cout/2)) * sigmoid(rows [Cout/2, Cout)) of interleaved 32-row tiles (then the output
+ * has Cout / 2 rows; commons.py:100-107; no residual with the gate); then + res [B][rows][T], then * mask when mask_out.  K odd,
+ * (K - 1) * dilation + 3 <= 64.  split_f16 = 1: fp32-accurate split-f16 MFMA (the default path of the library),
+ * 0: f32 MFMA.  Reference: torch.nn.Conv1d as used in attentions.py:138-145, 277-285, modules.py:148-176. */
+int vsp_conv1d(void* stream, int B, int T, int Cin, int Cout, int K, int dilation, const float* x, const float* w_host,
+               const float* bias_host, const int64_t* lengths, int mask_in, int in_act, float in_slope, int act,
+               const float* res, int mask_out, int split_f16, float* out);
 /* vsp_cl_resblock: ResBlock1.forward without the mask (reference modules.py:210-223):
  *   for p < n_pairs:  x = x + conv2_p(lrelu(conv1_p(lrelu(x), dilations[p]))), slope 0.1
  * w_host[2 p], w_host[2 p + 1] = conv1_p, conv2_p dense [C][C][K]; bias_host likewise [C].

@@ -119,3 +119,44 @@ def test_cl_ops_refuse_what_they_cannot_do(lib):
     w128 = np.zeros((128, 128, 3), dtype=np.float32)
     assert lib.vsp_cl_resblock(stream, 1, 8, 128, 3, 1, d, P(x128), host_ptrs([w128, w128]), host_ptrs([w128, w128]), 1, 3, P(o128)) == -7   # pairs: 32 / 64 channels
     assert lib.vsp_cl_resblock(stream, 1, 0, 32, 3, 1, d, P(x), host_ptrs([w, w]), host_ptrs([w, w]), 2, 3, P(out)) == 0         # empty
+
+
+@pytest.mark.parametrize("cin,cout,k,dil,act", [(192, 192, 1, 1, 0), (192, 384, 5, 1, 2), (1, 192, 3, 1, 0), (192, 1, 1, 1, 0),
+                                                (192, 2, 3, 1, 0), (80, 192, 5, 1, 1), (768, 192, 3, 1, 0), (192, 768, 3, 1, 1),
+                                                (96, 192, 1, 1, 0), (192, 128, 7, 2, 0), (33, 65, 3, 1, 1), (192, 384, 3, 3, 2)])
+@pytest.mark.parametrize("b,t", [(1, 4), (3, 60), (2, 128), (2, 132), (1, 488), (1, 1100)])
+def test_conv1d_matches_torch(lib, cin, cout, k, dil, act, b, t):
+    """The frame-rate convolution kernel (conv1d_f32_mfma: split-f16 with the LDS-DMA weight ring, and the f32 MFMA
+    form) with its fused prologue / epilogue on ragged channel and row counts, one-row outputs, the WN gate, input and
+    output masks, residual.  Reference semantics: masked Conv1d of attentions.py:277-285 / modules.py:148-176."""
+    r = np.random.Generator(np.random.PCG64(cin * 7 + cout * 3 + k + t))
+    x = r.standard_normal((b, cin, t)).astype(np.float32)
+    w = (r.standard_normal((cout, cin, k)) / np.sqrt(cin * k)).astype(np.float32)
+    bias = r.standard_normal(cout).astype(np.float32)
+    rows = cout // 2 if act == 2 else cout
+    res = r.standard_normal((b, rows, t)).astype(np.float32)
+    lens = np.asarray([max(1, t - 3 * i - (i % 2)) for i in range(b)], dtype=np.int64)
+    xd, rd, ld = torch.from_numpy(x).cuda(), torch.from_numpy(res).cuda(), torch.from_numpy(lens).cuda()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    mask = (np.arange(t)[None, :] < lens[:, None]).astype(np.float64)[:, None, :]
+    for split, mask_in, in_act, use_res, mask_out in ((1, 1, 0, 1, 1), (1, 0, 1, 0, 0), (0, 1, 0, 1, 1)):
+        use_res = use_res and act != 2                  # (the gate has no residual operand)
+        out = torch.full((b, rows, t), float("nan"), device="cuda")
+        rc = lib.vsp_conv1d(stream, b, t, cin, cout, k, dil, P(xd), w.ctypes.data_as(C.c_void_p), bias.ctypes.data_as(C.c_void_p),
+                            P(ld), mask_in, in_act, 0.1, act, P(rd) if use_res else None, mask_out, split, P(out))
+        assert rc == 0, (split, rc)
+        xt = torch.from_numpy(x).double()
+        if mask_in:
+            xt = xt * torch.from_numpy(mask)
+        if in_act:
+            xt = F.leaky_relu(xt, 0.1)
+        y = F.conv1d(xt, torch.from_numpy(w).double(), torch.from_numpy(bias).double(), dilation=dil, padding=dil * (k - 1) // 2)
+        if act == 1:
+            y = torch.relu(y)
+        elif act == 2:
+            y = torch.tanh(y[:, :rows]) * torch.sigmoid(y[:, rows:])
+        if use_res:
+            y = y + torch.from_numpy(res).double()
+        if mask_out:
+            y = y * torch.from_numpy(mask)
+        assert rel_err(out.cpu().numpy(), y.numpy()) <= TOL, (split, mask_in, in_act, use_res, mask_out)

@@ -91,6 +91,7 @@ SIGNATURES = {
     "vsp_mel_filterbank": (_I, [_I, _I, _I, _F, _F, _P]),
     "vsp_spec_to_mel": (_I, [_P, _I, _I, _I, _I, _I, _F, _F, _P, _P]),
     "vsp_cl_conv1d": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _F, _P, _I, _P]),
+    "vsp_conv1d": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _F, _I, _P, _I, _I, _P]),
     "vsp_cl_resblock": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P]),
     "vsp_profile_enable": (_I, [_P, _I]),
     "vsp_profile_read": (_I, [_P, C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), _I]),

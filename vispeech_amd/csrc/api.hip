@@ -1490,6 +1490,52 @@ int vsp_cl_conv1d(void* stream, int B, int T, int Cin, int Cout, int K, int dila
   return op_rc(e);
 }
 
+int vsp_conv1d(void* stream, int B, int T, int Cin, int Cout, int K, int dilation, const float* x, const float* w_host,
+               const float* bias_host, const int64_t* lengths, int mask_in, int in_act, float in_slope, int act,
+               const float* res, int mask_out, int split_f16, float* out) {
+  if (!x || !w_host || !out || B < 0 || T < 0 || act < 0 || act > 2 || ((mask_in || mask_out) && !lengths) || (act == 2 && res))
+    return VSP_ERR_ARG;
+  if (Cin <= 0 || Cout <= 0 || K < 1 || !(K & 1) || dilation < 1 || (K - 1) * dilation + 3 > CONV_HALO ||
+      (act == 2 && Cout % 64) || (T & 3))          // (rows of T floats must stay 16-byte aligned for the vector staging)
+    return VSP_ERR_UNSUPPORTED;
+  if (B == 0 || T == 0) return VSP_OK;
+  hipStream_t s = (hipStream_t)stream;
+  // the gate reads its tanh / sigmoid halves from interleaved 32-row tiles (weights.cpp packs WN in_layers the same way)
+  std::vector<float> wd((size_t)Cout * Cin * K), bd(Cout, 0.f);
+  for (int r = 0; r < Cout; ++r) {
+    int src = r;
+    if (act == 2) { const int tile = r / 32, in = r % 32; src = (tile & 1) * (Cout / 2) + (tile >> 1) * 32 + in; }
+    std::memcpy(&wd[(size_t)r * Cin * K], w_host + (size_t)src * Cin * K, (size_t)Cin * K * sizeof(float));
+    if (bias_host) bd[r] = bias_host[src];
+  }
+  std::vector<float> packed(packed_conv_floats(Cout, Cin, K));
+  if (split_f16) pack_conv_weights_f16s(packed.data(), Cout, Cin, K, wd.data());
+  else pack_conv_weights(packed.data(), Cout, Cin, K, wd.data());
+  DevBuf w, bias;
+  hipError_t e = w.alloc(packed.size() * 4);
+  if (e == hipSuccess) e = bias.alloc((size_t)Cout * 4);
+  if (e == hipSuccess) e = hipMemcpyAsync(w.p, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(bias.p, bd.data(), (size_t)Cout * 4, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) return op_rc(e);
+  const int rows_out = act == 2 ? Cout / 2 : Cout;
+  ConvArgs a;
+  std::memset(&a, 0, sizeof a);
+  a.x = x; a.x_bs = (long)Cin * T; a.x_cs = T;
+  a.wp = static_cast<const float*>(w.p); a.bias = static_cast<const float*>(bias.p);
+  a.out = out; a.o_bs = (long)rows_out * T; a.o_cs = T;
+  a.res = res; a.r_bs = (long)rows_out * T; a.r_cs = T;
+  a.lengths = lengths;
+  a.Cin = Cin; a.M = Cout; a.K = K; a.dil = dilation; a.pad = dilation * (K - 1) / 2;
+  a.T_in = T; a.Nq = T; a.nchunks = (Cin + CONV_CK - 1) / CONV_CK;
+  a.in_mask = mask_in ? 1 : 0; a.in_act = in_act ? 1 : 0; a.in_slope = in_slope;
+  a.act = act; a.alpha = 1.f; a.div = 1.f; a.mask_post = mask_out ? 1 : 0;
+  a.f16s = split_f16 ? 1 : 0;
+  e = launch_conv(a, B, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  return op_rc(e);
+}
+
 int vsp_cl_resblock(void* stream, int B, int T, int C, int K, int n_pairs, const int* dilations, const float* x,
                     const float* const* w_host, const float* const* bias_host, int mode, int terms, float* out) {
   if (!x || !w_host || !bias_host || !dilations || !out || x == out || B < 0 || T < 0 || n_pairs < 1 || n_pairs > 8 ||
