@@ -9,9 +9,10 @@
 //   * the input tile x[ci chunk][t0-pad .. t0+BN+(K-1)dil) is staged ONCE per chunk into LDS with the
 //     prologue (mask, leaky-relu) applied at staging time, so every tap re-reads activated values
 //     from LDS (conflict-free: a half-wave reads 32 consecutive floats of one row);
-//   * the weights never touch LDS: they are pre-packed on the host in A-fragment order so that a
-//     wave fetches four k-steps of one 32-row tile with a single coalesced 1 KiB global_load_dwordx4
-//     (L2-resident; prefetched one tap ahead);
+//   * the weights are pre-packed on the host in A-fragment order (4 KiB per 32-row tile, chunk and tap).  f32 form:
+//     a wave fetches four k-steps of one tile with a single coalesced 1 KiB global_load_dwordx4, one tap ahead,
+//     straight into registers.  Split-f16 form (the default): the block's slice of a step is copied once by
+//     LDS-DMA into a three-slot ring two steps ahead and read as ds_read_b128 fragments (RING, below);
 //   * the epilogue (bias, conditioning, relu / WN gate, masks, residual, accumulate, divide,
 //     polyphase scatter) runs on the accumulators, so every conv layer is one HBM read + one write.
 //
