@@ -111,6 +111,9 @@ def lib() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
             "g.build()'` (or `make -C vispeech_amd/csrc`). There is no CPU fallback for the synthesis path.")
+    # One HIP runtime per process: torch ships its own libamdhip64; loaded AFTER a copy this library pulled in from
+    # /opt/rocm, the two runtimes do not share a device context ("no ROCm-capable device" at the first hipMemcpy).
+    import torch  # noqa: F401
     try:
         l = C.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover
