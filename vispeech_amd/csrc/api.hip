@@ -269,13 +269,12 @@ void run_wn(Run& r, const Conv& cond, const std::vector<Conv>& in, const std::ve
     a.act = 2; a.cond = gc ? gc + (size_t)l * 2 * h : nullptr; a.cond_bs = 2L * h * nl;
     r.conv(a, B);
     if (l < nl - 1) {
-      // skip first (reads ACT only), then the in-place residual update of H
-      a = r.args(skip[l], ACT, OUT, T, T);
-      a.acc_prev = l > 0;
-      r.conv(a, B);
+      // res_skip_layers[l] (modules.py:165-172) as one launch with two destinations: rows [0, h) are the in-place
+      // residual update H = (H + res) * mask, rows [h, 2 h) accumulate into the skip sum
       a = r.args(res[l], ACT, H, T, T);
       a.res = H.p; a.r_bs = H.bs; a.r_cs = H.cs;
       a.lengths = lengths; a.mask_post = 1;
+      a.split_row = h; a.out2 = OUT.p; a.o2_bs = OUT.bs; a.o2_cs = OUT.cs; a.acc_prev2 = l > 0;
       r.conv(a, B);
     } else {
       a = r.args(skip[l], ACT, OUT, T, T);

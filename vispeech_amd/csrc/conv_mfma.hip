@@ -534,6 +534,8 @@ __global__ void __launch_bounds__(64 * WM * WN, F16S ? 2 : 1) conv1d_f32_mfma(Co
       }
       return;
     }
+    const __amdgpu_buffer_rsrc_t ro2 = __builtin_amdgcn_make_buffer_rsrc(
+        a.split_row ? a.out2 + (size_t)b * a.o2_bs : outb, 0, OOR, 0x00020000);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int mtile = mtile0 + mt;
@@ -543,6 +545,30 @@ __global__ void __launch_bounds__(64 * WM * WN, F16S ? 2 : 1) conv1d_f32_mfma(Co
       for (int g = 0; g < 4; ++g) {
         row_vec(a.bias, mtile * 32 + 8 * g + 4 * h, bv[g]);
         row_vec(condb, mtile * 32 + 8 * g + 4 * h, cv[g]);
+      }
+      if (a.split_row && mtile * 32 >= a.split_row) {
+        // second destination: out2[row - split_row] = conv + bias (+ out2)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int q = t0 + (wn * NT + nt) * 32 + l31;
+          const bool qin = q < a.Nq;
+          int oo[16];
+          unsigned pv[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = mtile * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+            oo[r] = (qin && row < a.M) ? ((row - a.split_row) * (int)a.o2_cs + q) * 4 : OOR;
+            pv[r] = __builtin_amdgcn_raw_buffer_load_b32(ro2, a.acc_prev2 ? oo[r] : OOR, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = acc[mt][nt][r];
+            if (a.bias) v += bv[r >> 2][r & 3];
+            if (a.acc_prev2) v += __uint_as_float(pv[r]);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro2, oo[r], 0, 0);
+          }
+        }
+        continue;
       }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
@@ -676,7 +702,9 @@ static hipError_t launch_tile(const ConvArgs& a, int B, hipStream_t s) {
 }
 
 hipError_t launch_conv(const ConvArgs& a, int B, hipStream_t s) {
-  if ((a.K - 1) * a.dil + 3 > CONV_HALO || a.K < 1 || a.Nq <= 0 || B <= 0) return hipErrorInvalidValue;
+  if ((a.K - 1) * a.dil + 3 > CONV_HALO || a.K < 1 || a.Nq <= 0 || B <= 0 || (a.split_row & 31) ||
+      (a.split_row && (a.ups_s > 0 || a.act == 2 || !a.out2)))
+    return hipErrorInvalidValue;
   const bool gate = a.act == 2;
   static int ring = -1;   // VSP_FRAME_RING=0: weights from global memory into registers (the round-1 form of these kernels)
   if (ring < 0) { const char* e = getenv("VSP_FRAME_RING"); ring = e ? atoi(e) != 0 : 1; }

@@ -36,6 +36,10 @@ struct ConvArgs {
   int mask_post;
   int ups_s, ups_p, T_store;  // transposed-conv store: row=(co,r), n = s*q + r - p in [0,T_store)
   int f16s;                   // weights packed by pack_conv_weights_f16s: split-f16 MFMA path
+  // two destinations (WN res_skip layer, reference modules.py:165-172, as ONE launch): rows >= split_row (a multiple of
+  // 32; 0 = off) go to out2[row - split_row] (+ out2 when acc_prev2) with no residual, mask or scaling; the rows
+  // below it keep the epilogue above
+  int split_row; float* out2; long o2_bs, o2_cs; int acc_prev2;
 };
 
 // the tile shape is chosen from M and Nq

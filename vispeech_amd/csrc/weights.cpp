@@ -258,7 +258,7 @@ int plan_model(vsp_ctx* ctx) {
     F.cond = p.conv(2 * h * fl, gin, 1, 1, 0, true);
     for (int l = 0; l < fl; ++l) {
       F.in.push_back(p.conv(2 * h, h, fk, 1, (fk - 1) / 2, true));
-      if (l < fl - 1) F.res.push_back(p.conv(h, h, 1, 1, 0, true));
+      if (l < fl - 1) F.res.push_back(p.conv(2 * h, h, 1, 1, 0, true));   // residual rows, then skip rows: one launch
       F.skip.push_back(p.conv(h, h, 1, 1, 0, true));
     }
     F.post = p.conv(half, h, 1, 1, 0, true);
@@ -276,7 +276,7 @@ int plan_model(vsp_ctx* ctx) {
     Q.cond = p.conv(2 * h * ql, gin, 1, 1, 0, true);
     for (int l = 0; l < ql; ++l) {
       Q.in.push_back(p.conv(2 * h, h, fk, 1, (fk - 1) / 2, true));
-      if (l < ql - 1) Q.res.push_back(p.conv(h, h, 1, 1, 0, true));
+      if (l < ql - 1) Q.res.push_back(p.conv(2 * h, h, 1, 1, 0, true));
       Q.skip.push_back(p.conv(h, h, 1, 1, 0, true));
     }
     Q.proj_m = p.conv(inter, h, 1, 1, 0, true);
@@ -461,7 +461,7 @@ static inline int gate_row(int pr, int h) {
 }
 
 // modules.WN (reference modules.py:113-176): cond_layer rows and in_layer rows are permuted into
-// tanh/sigmoid tile pairs (gate_row); res_skip rows split into the residual and the skip conv.
+// tanh/sigmoid tile pairs (gate_row); a res_skip layer is one conv of 2 h rows with two destinations (ConvArgs::split_row).
 static void fill_wn(Filler& f, const std::string& p, const Conv& cond, const std::vector<Conv>& in,
                     const std::vector<Conv>& res, const std::vector<Conv>& skip, int nl, int h, int gin, int fk) {
   {
@@ -485,8 +485,8 @@ static void fill_wn(Filler& f, const std::string& p, const Conv& cond, const std
            [=](int r) { return bd[gate_row(r, h)]; });
     const std::string rs = p + ".res_skip_layers." + std::to_string(l);
     if (l < nl - 1) {
-      f.conv_plain(res[l], rs + ".weight", rs + ".bias", 0);
-      f.conv_plain(skip[l], rs + ".weight", rs + ".bias", h);
+      f.conv_plain(res[l], rs + ".weight", rs + ".bias", 0);      // all 2 h rows: residual half, skip half
+      f.conv_plain(skip[l], rs + ".weight", rs + ".bias", h);     // (the skip half alone: the two-launch form)
     } else {
       f.conv_plain(skip[l], rs + ".weight", rs + ".bias", 0);
     }
