@@ -77,7 +77,8 @@ def torch_resblock(x, ws, bs, dils, k):
 
 
 @pytest.mark.parametrize("c,k,dils", [(32, 3, (1, 3, 5)), (32, 7, (1, 3, 5)), (32, 11, (1, 3, 5)), (64, 3, (1, 3, 5)),
-                                      (64, 7, (1, 3)), (64, 11, (5,)), (32, 5, (2, 1, 4)), (32, 3, (1,))])
+                                      (64, 7, (1, 3)), (64, 11, (5,)), (32, 5, (2, 1, 4)), (32, 3, (1,)), (128, 3, (1,)),
+                                      (128, 3, (5,)), (128, 7, (3,))])
 @pytest.mark.parametrize("b,t", [(1, 1), (2, 131), (1, 256), (2, 489), (1, 1500)])
 def test_cl_resblock_three_implementations(lib, c, k, dils, b, t):
     r = np.random.Generator(np.random.PCG64(c + 10 * k + 100 * len(dils) + t))
@@ -89,13 +90,17 @@ def test_cl_resblock_three_implementations(lib, c, k, dils, b, t):
     darr = (C.c_int * len(dils))(*dils)
     outs = []
     for mode in (0, 1, 2):
+        if mode == 1 and c > 64:
+            outs.append(None)                       # (the pair kernel covers 32 / 64 channels)
+            continue
         out = torch.full((b, t, c), float("nan"), device="cuda")
         rc = lib.vsp_cl_resblock(stream, b, t, c, k, len(dils), darr, P(xd), host_ptrs(ws), host_ptrs(bs), mode, 3, P(out))
         assert rc == 0, mode
         outs.append(out.cpu())
     ref = torch_resblock(x, ws, bs, dils, k)
     assert rel_err(outs[0].numpy(), ref) <= TOL
-    assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
+    if outs[1] is not None:
+        assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
     assert torch.equal(outs[0], outs[2]), float((outs[0] - outs[2]).abs().max())
 
 

@@ -394,8 +394,9 @@ def test_reduced_precision_mode_is_opt_in_and_gated(dims, weights, golden_dir, m
 
 
 @pytest.mark.parametrize("env", [{"VSP_FUSE_PAIRS": "0"}, {"VSP_CHAIN": "0"}, {"VSP_CHAIN": "7", "VSP_CHAIN_CH": "64"},
-                                 {"VSP_CHAIN_WAVES": "4"}, {"VSP_CHAIN_WAVES": "8"}],
-                         ids=["two_launches", "pair_launches", "chains_64ch_too", "chains_256col", "chains_512col"])
+                                 {"VSP_CHAIN_WAVES": "4"}, {"VSP_CHAIN_WAVES": "8"}, {"VSP_CHAIN128": "7"}],
+                         ids=["two_launches", "pair_launches", "chains_64ch_too", "chains_256col", "chains_512col",
+                              "pairs_128ch_fused"])
 def test_fused_resblock_paths_are_bit_identical(net, dims, weights, monkeypatch, env):
     """The ResBlocks of the 32/64-channel stages run fused (gen16.hip): by default a whole ResBlock of the
     32-channel stage is ONE launch (g16_chain: the running x in registers, every intermediate in LDS, the chain's halo

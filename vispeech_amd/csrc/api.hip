@@ -97,17 +97,19 @@ struct Run {
     ctx->prof_bytes_ext[cls] += bytes_ext;
   }
   // fused ResBlock1 chain (g16_chain, gen16.hip): all dilation pairs of one ResBlock in one launch
-  void clchain(const ResBlockW& rb, int ch, const float* x, float* out, long bs, int T, bool acc_prev, float div, int B) {
+  // (pairs [p0, p0 + np) of the ResBlock: the whole block by default)
+  void clchain(const ResBlockW& rb, int ch, const float* x, float* out, long bs, int T, bool acc_prev, float div, int B,
+               int p0 = 0, int np = -1) {
     if (dry() || !ok()) return;
     ClChainArgs a;
     std::memset(&a, 0, sizeof a);
-    const int np = (int)rb.dil.size();
+    if (np < 0) np = (int)rb.dil.size();
     a.x = x; a.x_bs = bs; a.out = out; a.o_bs = bs;
     for (int p = 0; p < np; ++p) {
-      a.w[2 * p] = reinterpret_cast<const uint16_t*>(A(rb.h1[p].wg));
-      a.w[2 * p + 1] = reinterpret_cast<const uint16_t*>(A(rb.h2[p].wg));
-      a.b[2 * p] = A((size_t)rb.h1[p].b); a.b[2 * p + 1] = A((size_t)rb.h2[p].b);
-      a.dil[p] = rb.dil[p];
+      a.w[2 * p] = reinterpret_cast<const uint16_t*>(A(rb.h1[p0 + p].wg));
+      a.w[2 * p + 1] = reinterpret_cast<const uint16_t*>(A(rb.h2[p0 + p].wg));
+      a.b[2 * p] = A((size_t)rb.h1[p0 + p].b); a.b[2 * p + 1] = A((size_t)rb.h2[p0 + p].b);
+      a.dil[p] = rb.dil[p0 + p];
     }
     a.np = np; a.C = ch; a.K = rb.k; a.T = T;
     a.slope = 0.1f;                                    // modules.LRELU_SLOPE (reference modules.py:17)
@@ -492,6 +494,11 @@ void run_generator_cl(Run& r, int B, int T, T3 z, const int64_t* in_lengths, con
             const float* yin = d == 0 ? xu : ((d & 1) ? ya : t1);
             float* yout = last ? xs : ((d & 1) ? t1 : ya);
             r.clpair(rb.h1[d], rb.h2[d], yin, yout, bs, (int)Tout, last && j > 0, div, nb);
+          } else if (ch == 128 && (r.ctx->chain128_mask & kbit) && g16_chain_supported(ch, rb.k, &rb.dil[d], 1)) {
+            // 128-channel pair as ONE launch (g16_chain, 128-column blocks): the intermediate never reaches HBM
+            const float* yin = d == 0 ? xu : ((d & 1) ? ya : t1);
+            float* yout = last ? xs : ((d & 1) ? t1 : ya);
+            r.clchain(rb, ch, yin, yout, bs, (int)Tout, last && j > 0, div, nb, d, 1);
           } else {
             const float* yin = d == 0 ? xu : ya;
             r.clconv(rb.h1[d], yin, bs, t1, bs, nullptr, 0, (int)Tout, (int)Tout, (int)Tout, 0.1f, false, 1.f, nb);
@@ -552,6 +559,7 @@ int vsp_create(const vsp_config* cfg, int device, vsp_ctx** out) {
   if (const char* e = getenv("VSP_FUSE_PAIRS")) ctx->fuse_pairs = atoi(e) != 0;
   if (const char* e = getenv("VSP_CHAIN")) ctx->chain_mask = atoi(e);
   if (const char* e = getenv("VSP_CHAIN_CH")) ctx->chain_ch = atoi(e);
+  if (const char* e = getenv("VSP_CHAIN128")) ctx->chain128_mask = atoi(e);
   *out = ctx;  // returned even on failure so that vsp_last_error can be read; caller destroys it
   return rc;
 }

@@ -1020,7 +1020,7 @@ __global__ void __launch_bounds__(64 * NWV, 2) g16_chain(ClChainArgs a) {
       read_a(std::integral_constant<int, 1 - pp>{}, a_addr);
       g16_for<NW>([&](auto J) {
         // in flight behind the fragments this n-tile needs: the other n-tiles' refills and the next A set
-        g16_lgkmcnt<RA + (NW - 1) * RB>();
+        g16_lgkmcnt<(RA + (NW - 1) * RB < 15 ? RA + (NW - 1) * RB : 15)>();   // (a 4-bit counter)
         mfma_col(P, J);
         read_b(J, b_addr);
       });
@@ -1127,10 +1127,11 @@ static int g16_chain_halo(int K, const int* dil, int np) {
 }
 
 bool g16_chain_supported(int C, int K, const int* dil, int np) {
-  if (!(C == 32 || C == 64) || np < 1 || np > 3 || K < 1 || !(K & 1)) return false;
+  if (!(C == 32 || C == 64 || C == 128) || np < 1 || np > 3 || K < 1 || !(K & 1)) return false;
   for (int p = 0; p < np; ++p)
     if (dil[p] < 1 || dil[p] * ((K - 1) / 2) > G16_HALO / 2) return false;
-  return 256 - 2 * g16_chain_halo(K, dil, np) >= 32;
+  // 128 channels: 128-column blocks (the four chunk images and the ring fill the LDS)
+  return (C == 128 ? 128 : 256) - 2 * g16_chain_halo(K, dil, np) >= 32;
 }
 
 hipError_t launch_g16_chain(const ClChainArgs& a0, int B, hipStream_t s) {
@@ -1146,6 +1147,7 @@ hipError_t launch_g16_chain(const ClChainArgs& a0, int B, hipStream_t s) {
   if (force < 0) { const char* e = getenv("VSP_CHAIN_WAVES"); force = e ? atoi(e) : 0; }
   const bool wide = a.C == 32 && (force ? force == 8 : 2 * a.halo > 64);
   // <NCH, NW, G, TERMS, NWV>
+  if (a.C == 128) return a.terms == 1 ? launch_g16_chain_tile<4, 1, 1, 1, 8>(a, B, s) : launch_g16_chain_tile<4, 1, 1, 3, 8>(a, B, s);
   if (a.terms == 1) {
     if (a.C == 64) return launch_g16_chain_tile<2, 2, 2, 1, 8>(a, B, s);
     return wide ? launch_g16_chain_tile<1, 4, 4, 1, 8>(a, B, s) : launch_g16_chain_tile<1, 4, 2, 1, 4>(a, B, s);

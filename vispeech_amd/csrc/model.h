@@ -121,6 +121,7 @@ struct vsp_ctx {
   size_t att_scratch_bytes = 0;  // path takes them from the caller's workspace)
   int att_ksplit = -1;     // attention key-split blocks: -1 automatic (under-filled grids), 0 never, 1 always (VSP_ATT_KSPLIT)
   int chain_mask = 0x1;    // ResBlock chains (all dilation pairs of a ResBlock in one launch): bit 0 = k3, 1 = k7, 2 = k11 (VSP_CHAIN=<mask>; measured: only k3 pays)
+  int chain128_mask = 0;   // conv PAIRS of the 128-channel stage as one launch each (g16_chain, one pair): bit 0 = k3, 1 = k7, 2 = k11 (VSP_CHAIN128)
   int chain_ch = 32;       // widest stage that runs chains (VSP_CHAIN_CH)
   bool fuse_pairs = true;  // ResBlock conv pairs of the 32/64-channel stages as one launch (VSP_FUSE_PAIRS=0: two launches)
   double chunk_mb = 0.0;   // generator batch chunk in MiB per activation tensor (VSP_CHUNK_MB; 0 = whole batch: measured faster)
