@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel register / spill / occupancy table of one HIP source (compile only, no GPU needed).
-usage: tools/kernel_regs.py vispeech_amd/csrc/conv_f16s.hip [extra hipcc flags]"""
+usage: tools/kernel_regs.py vispeech_amd/csrc/gen16.hip [extra hipcc flags]"""
 import re
 import subprocess
 import sys
