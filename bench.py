@@ -50,8 +50,8 @@ WL_TEXT = {"C1": "zh utterance (~5 s)", "C2": "zh utterances (~5 s each)", "C3":
 def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=3)
-    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--workload", default="C3")
     p.add_argument("--batch", type=int, default=None,
                    help="override the batch: utterances per GPU (C3 and the other per-rank workloads) or of the GLOBAL batch (C4)")
