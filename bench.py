@@ -61,6 +61,10 @@ def parse(argv=None):
     p.add_argument("--profile-steps", type=int, default=2, help="untimed steps with per-launch events (roofline)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample", type=int, default=16, help="utterances of the batch timed on the CPU oracle")
+    p.add_argument("--cpu-runs", type=int, default=3, help="timed CPU-oracle runs (the median is reported) after one warm-up run")
+    p.add_argument("--dist", action="store_true",
+                   help="initialise torch.distributed (RCCL) even at --gpus 1: the weight broadcast, the frame-count "
+                        "all-reduce and the waveform gather run through the collectives with one rank")
     return p.parse_args(argv)
 
 
@@ -96,7 +100,27 @@ def usable_cores() -> int:
     return max(1, min(avail, 32))
 
 
-def cpu_baseline_and_parity(sd, dims, batch, n_utt, controls, tf_global, noise_global, gpu_out):
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def lib_sha256() -> str:
+    import hashlib
+    from vispeech_amd import _lib
+    h = hashlib.sha256()
+    with open(_lib.LIB_PATH, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def cpu_baseline_and_parity(sd, dims, batch, n_utt, controls, tf_global, noise_global, gpu_out, runs=3):
     """The parity-pinned CPU restatement (oracle/, kind 'port') on the first n_utt utterances of the same batch,
     padded exactly like the GPU run (global T_p and T_f, gotchas G5 / G6) so that its waveform is THE reference for
     the GPU output of those utterances.  Returns (cpu_baseline, parity)."""
@@ -113,19 +137,25 @@ def cpu_baseline_and_parity(sd, dims, batch, n_utt, controls, tf_global, noise_g
     if controls == "all":
         kw["pitch_control"] = batch["f0"][sl]
         kw["energy_control"] = batch["energy"][sl]
-    # tiny warm-up (thread pool, mkldnn primitives)
-    orc.infer(batch["phonemes"][:1, :4], np.array([4]), batch["sid"][:1], noise=batch["noise"][:1, :, :8],
-              noise_scale=0.667, duration_control=np.full((1, 4), 2.0, dtype=np.float32),
-              pitch_control=batch["f0"][:1, :4], energy_control=batch["energy"][:1, :4])
-    t0 = time.perf_counter()
-    ref = orc.infer(batch["phonemes"][sl], batch["lengths"][sl], batch["sid"][sl], noise=noise_global[sl],
-                    t_f=tf_global, **kw)
-    dt = time.perf_counter() - t0
+    # warm-up run (1 warm-up + median of >= 3): the same call on the first two utterances --
+    # thread pool, mkldnn primitives and the allocator see the real shapes
+    w = slice(0, min(2, n_utt))
+    orc.infer(batch["phonemes"][w], batch["lengths"][w], batch["sid"][w], noise=noise_global[w], t_f=tf_global,
+              **{k: (v[w] if isinstance(v, np.ndarray) else v) for k, v in kw.items()})
+    times, ref = [], None
+    for _ in range(max(1, runs)):
+        t0 = time.perf_counter()
+        ref = orc.infer(batch["phonemes"][sl], batch["lengths"][sl], batch["sid"][sl], noise=noise_global[sl],
+                        t_f=tf_global, **kw)
+        times.append(time.perf_counter() - t0)
+    dt = float(np.median(times))
     frames = np.asarray(gpu_out["frames"][sl], dtype=np.int64)
     samples = 512 * int(frames.sum())
     base = {"value": samples / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "cpu_model": cpu_model(), "host_threads": os.cpu_count(), "torch_threads": cores,
+            "runs_s": [round(t, 2) for t in times], "timing": f"1 warm-up run + median of {len(times)} timed runs",
             "sample": f"first {n_utt} utterances of the same batch, padded to the batch's {tf_global} frames "
-                      f"({samples} valid samples, {dt:.1f} s, oracle/vispeech_oracle.py on torch CPU fp32, {cores} threads)",
+                      f"({samples} valid samples, median {dt:.1f} s, oracle/vispeech_oracle.py on torch CPU fp32, {cores} threads)",
             "rtf": dt / (samples / 44100.0)}
     # parity of the very utterances the timed run produced (outside the timed region)
     ro = ref["o"].numpy()
@@ -146,9 +176,31 @@ def cpu_baseline_and_parity(sd, dims, batch, n_utt, controls, tf_global, noise_g
     return base, par
 
 
+def c5_prefix_parity(sd, dims, batch, last, tf_global, frames=600):
+    """Long-form workload: the CPU oracle's vocoder on the first `frames` frames of the GPU's own z (the generator is
+    local: samples further than its receptive field -- 14 frames -- from the cut are exact) against the same samples
+    of the GPU waveform; the frame-rate stages are covered by z itself in tests/test_baseline_configs.py."""
+    import numpy as np
+    import torch
+    from oracle.vispeech_oracle import Oracle, generator
+    orc = Oracle(sd, dims)
+    n = min(frames, tf_global)
+    z = last["z"][:1, :, :n].cpu()
+    g = orc.w["emb_g.weight"][torch.as_tensor(batch["sid"][:1])].unsqueeze(-1)
+    torch.set_num_threads(usable_cores())
+    t0 = time.perf_counter()
+    ref = generator(orc.w, z, g, dims).numpy()
+    dt = time.perf_counter() - t0
+    keep = 512 * (n - (16 if n < tf_global else 0))
+    got = last["o"][:1, :, :keep].cpu().numpy()
+    err = float(np.abs(got - ref[:, :, :keep]).max() / max(np.abs(ref).max(), 1e-30))
+    return {"what": f"oracle vocoder on frames [0, {n}) of the GPU's z vs the GPU waveform, first {keep} samples",
+            "max_rel_err": err, "tolerance": 1e-4, "ok": bool(err <= 1e-4), "oracle_s": round(dt, 1)}
+
+
 def main():
     args = parse()
-    if "RANK" not in os.environ and args.gpus > 1:
+    if "RANK" not in os.environ and (args.gpus > 1 or args.dist):
         sys.exit(self_launch(args))
     import numpy as np
     import torch
@@ -162,7 +214,7 @@ def main():
     from vispeech_amd import _lib, config as vcfg
     from vispeech_amd.models import SynthesizerTrn
     from vispeech_amd.schema import ModelDims
-    from vispeech_amd.sharding import broadcast_weights, gather_batch, global_max, shard_range
+    from vispeech_amd.sharding import BatchGatherer, broadcast_weights, global_max, shard_counts, shard_range
     from vispeech_amd.synth import WORKLOADS, synth_batch, synth_state_dict
 
     # one process per GPU; VSP_BENCH_BACKEND=gloo (test hook) lets several ranks share one GPU to exercise the
@@ -171,18 +223,20 @@ def main():
     dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    use_dist = world > 1 or args.dist          # --dist: the collectives run (through RCCL) even with one rank
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    n_ranks_seen = dist.get_world_size() if use_dist else 1
 
     dims = ModelDims()
     a, kw = vcfg.synthesizer_args(vcfg.default_hparams())
     net = SynthesizerTrn(*a, device=dev, **kw).eval()
     sd = synth_state_dict(dims, seed=1234, infer_only=True) if rank == 0 or world == 1 else None
-    if world == 1:
+    if not use_dist:
         net.load_state_dict(sd)
     else:
         # RCCL weight broadcast: rank 0 packs, everyone else adopts the broadcast arena and checks its header
@@ -228,27 +282,36 @@ def main():
     noise = t(noise_np[sl] if sharded_global else noise_np)
 
     last = {}
+    # final waveform gather on rank 0 (RCCL over xGMI): shard sizes are known from shard_range, the receive buffers
+    # are persistent, and the collective runs on a side stream so that step k + 1 overlaps the gather of step k
+    gatherer = None
+    if use_dist:
+        counts = shard_counts(B_all, world) if sharded_global else [B] * world
+        gatherer = BatchGatherer(counts, (1, 512 * tf_global), torch.float32, dev, dst=0)
 
     def step():
         o, x_mask, (z, z_p, m_p, logs_p), duration, f0, energy = net.infer(
             ph, ln, sid=sid, noise_scale=0.667, noise=noise, t_f=tf_global, **ctl)
-        if world > 1:
-            gather_batch(o, dst=0)          # final waveform gather on rank 0 (RCCL)
+        if gatherer is not None:
+            gatherer.start(o)
         last.update(o=o, z=z, duration=duration)
         return o
+
+    def drain():
+        if gatherer is not None:
+            gatherer.wait()                 # the last gather belongs to the timed region
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
 
     for _ in range(args.warmup):
         step()
     eng.profile(False)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    drain()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    drain()
     dt = time.perf_counter() - t0
 
     # ---- second, untimed pass: HIP events around every launch of the profiled classes (rank 0's numbers are reported)
@@ -257,17 +320,17 @@ def main():
         eng.profile(True)
         for _ in range(args.profile_steps):
             step()
-        torch.cuda.synchronize()
+        drain()
         for name, cls in (("generator", _lib.PROF_GENERATOR), ("attention", _lib.PROF_ATTENTION), ("frame", _lib.PROF_FRAME)):
             n, ms, fl, by, bx = eng.profile_read(reset=True, cls=cls)
             prof[name] = dict(launches=n // args.profile_steps, ms=ms / args.profile_steps, flops=fl / args.profile_steps,
                               bytes=by / args.profile_steps, bytes_ext=bx / args.profile_steps)
         eng.profile(False)
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     tt = torch.tensor([dt, float(valid_samples)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         mx = tt.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = tt.clone()
@@ -294,6 +357,9 @@ def main():
                        "utterances_per_gpu": B, "global_batch": B_all * (1 if sharded_global else world),
                        "padded_frames": tf_global, "valid_samples_per_step": int(total_valid),
                        "parallelism": f"shard{world}", "generator": gen_mode, "controls": args.controls},
+            "n_ranks_seen": n_ranks_seen,
+            "collectives": (f"torch.distributed backend {dist.get_backend()}: weight-arena broadcast, frame-count all-reduce MAX, "
+                            "waveform gather on rank 0 (side stream, persistent buffers)") if use_dist else "none (one process, no process group)",
         }
         if gen_mode == "f32":
             out["dtype"] = "f32"
@@ -315,7 +381,7 @@ def main():
                 "traffic": None,
                 "kernel": "generator convolutions (g16_conv; g16_pair / g16_chain: fused ResBlock pairs / whole ResBlocks on the 64/32-channel stages), rank 0",
                 "launches": g["launches"], "kernel_ms_per_step": g["ms"], "avg_launch_ms": g["ms"] / max(g["launches"], 1),
-                "alg_tflops": tfl, "alg_flops_per_launch": g["flops"] / max(g["launches"], 1),
+                "alg_tflops": tfl, "alg_frac": tfl / peak, "alg_flops_per_launch": g["flops"] / max(g["launches"], 1),
                 "alg_gbs": gbs, "alg_bytes_per_launch": g["bytes"] / max(g["launches"], 1),
                 "alg_gbs_with_residual_reads": g["bytes_ext"] / (g["ms"] * 1e-3) / 1e9 if g["ms"] > 0 else 0.0,
                 "hbm_frac": f_hbm, "mfma_issue_frac": f_mfma,
@@ -344,28 +410,31 @@ def main():
                                             "alg_tflops": fr["flops"] / (fr["ms"] * 1e-3) / 1e12}
             # measured HBM traffic of the generator launches from an earlier rocprofv3 --pmc pass of THIS build and
             # workload (profiles/traffic.json: keyed on generator mode, utterances and padded frames)
+            # and on the SHA-256 of the library the passes ran: a rebuilt library drops the stale figure instead of carrying it)
             traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(traffic_file) and not any(os.environ.get(k) for k in ("VSP_LIB_PATH", "VSP_FUSE_PAIRS", "VSP_CHUNK_MB", "VSP_CHAIN_CH",
-                                                                                     "VSP_CHAIN_WAVES", "VSP_PAIR_WAVES", "VSP_G16_ROWS")):
+            if os.path.exists(traffic_file) and not any(os.environ.get(k) for k in ("VSP_FUSE_PAIRS", "VSP_CHAIN")):
                 try:
                     tr = json.load(open(traffic_file))
                     if tr.get("generator") == gen_mode and tr.get("utterances") == B and tr.get("padded_frames", tf_global) == tf_global \
-                            and tr.get("kernels") == "g16c" + os.environ.get("VSP_CHAIN", "1"):
+                            and tr.get("lib_sha256") == lib_sha256():
                         roof["traffic"] = tr["hbm_bytes_per_launch"]
                         roof["traffic_source"] = "previous PMC pass: " + str(tr.get("source"))
                         roof["hbm_measured_gbs"] = tr["hbm_bytes_per_launch"] * tr.get("launches_per_step", g["launches"]) / (g["ms"] * 1e-3) / 1e9
                 except Exception:
                     pass
             out["roofline"] = roof
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "C5":
+            out["parity"] = c5_prefix_parity(sd, dims, batch, last, tf_global)
+        elif world == 1 and not args.no_cpu_baseline:
             frames_all = frames_local
             gpu_out = dict(o=last["o"], z=last["z"], duration=last["duration"] if torch.is_tensor(last["duration"]) else ctl["duration_control"],
                            frames=frames_all)
             out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(
                 sd, dims, {k: v[sl] if isinstance(v, np.ndarray) and v.shape[:1] == (B_all,) else v for k, v in batch.items()},
-                min(args.cpu_sample, B), args.controls, tf_global, noise_np[sl] if sharded_global else noise_np, gpu_out)
+                min(args.cpu_sample, B), args.controls, tf_global, noise_np[sl] if sharded_global else noise_np, gpu_out,
+                runs=args.cpu_runs)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define VSP_ABI_VERSION 3
+#define VSP_ABI_VERSION 4
 
 enum {
   VSP_OK = 0,
@@ -151,12 +151,15 @@ int vsp_frame_lengths_host(vsp_ctx* ctx, void* stream, int B, const int64_t* fra
  * Tf = padded frame count of the batch (>= every frame length; the GLOBAL maximum in a sharded
  * run, SURVEY gotcha G6).  max_len < 0 = no truncation; the generator consumes
  * Tdec = min(Tf, max_len) frames and writes o[B][1][Tdec * prod(upsample_rates)].
- * noise [B][inter][Tf] (ignored if noise_scale == 0 and NULL).
+ * noise [B][inter][Tf], or NULL: then the library draws it on the device -- vsp_randn(noise_seed) over the same
+ * [B][inter][Tf] elements (ABI 4; the torch.randn_like(m_p) of models.py:718 for callers without a generator.  It is a
+ * Philox4x32-10 stream of its own, NOT bit-compatible with torch.manual_seed(noise_seed); pass the tensor to
+ * reproduce a torch run).  noise_seed is ignored when noise != NULL or noise_scale == 0.
  * Outputs (device, contiguous): o, x_mask[B*Tf] uint8, z, z_p, m_p, logs_p [B][inter][Tf]. */
 int64_t vsp_decode_workspace_bytes(const vsp_ctx* ctx, int B, int Tp, int Tf);
 int vsp_decode(vsp_ctx* ctx, void* stream, int B, int Tp, int Tf, int max_len,
                const float* x_var, const float* g, const int32_t* cum_dur, const int64_t* frame_lengths,
-               const float* noise, float noise_scale,
+               const float* noise, uint64_t noise_seed, float noise_scale,
                float* o, uint8_t* x_mask, float* z, float* z_p, float* m_p, float* logs_p,
                void* workspace, int64_t workspace_bytes);
 
@@ -170,7 +173,7 @@ int vsp_infer(vsp_ctx* ctx, void* stream, int B, int Tp, int tf_pad, int max_len
               const int64_t* phonemes, const int64_t* lengths, const int64_t* sid,
               const float* duration_ctl, const float* pitch_ctl, const float* energy_ctl,
               float duration_scale, float pitch_scale, float energy_scale,
-              const float* noise, float noise_scale,
+              const float* noise, uint64_t noise_seed, float noise_scale,
               float* o, uint8_t* x_mask, float* z, float* z_p, float* m_p, float* logs_p,
               float* duration, float* f0, float* energy, int64_t* frame_lengths,
               void* workspace, int64_t workspace_bytes);
@@ -179,9 +182,15 @@ int vsp_infer(vsp_ctx* ctx, void* stream, int B, int Tp, int tf_pad, int max_len
 /* MultiHeadAttention.attention (reference attentions.py:148-179 with the relative-position helpers
  * :181-243) of layer `layer` of encoder `which` (0 enc_p.encoder, 1 pitch_predictor.pitch_net,
  * 2 frame_prior_net.fft_block): qkv [B][3H][T] = conv_q | conv_k | conv_v outputs, lengths[B] (attn_mask =
- * mask x mask), out [B][H][T] = the tensor conv_o consumes.  No workspace. */
+ * mask x mask), out [B][H][T] = the tensor conv_o consumes.  workspace >= vsp_attention_workspace_bytes (the packed
+ * f16 operand images; ABI 4: caller-owned like every other workspace -- no allocation behind the ABI).
+ * Operand range of the default (split-f16) kernel: q, k, v are packed as f16 hi / lo pairs with fixed power-of-two
+ * scales (q * 128 log2(e) / sqrt(d_k), k * 16, v * 16); magnitudes beyond |q| ~ 3.4e3, |k|, |v| ~ 4.0e3 are CLAMPED
+ * to the largest finite f16 (the fp32 reference stays exact there; layer-normed encoder activations are O(1..10)).
+ * VSP_ATT=f32 selects the f32 kernel, which has no such limit. */
+int64_t vsp_attention_workspace_bytes(const vsp_ctx* ctx, int B, int T);
 int vsp_attention(vsp_ctx* ctx, void* stream, int which, int layer, int B, int T, const float* qkv,
-                  const int64_t* lengths, float* out);
+                  const int64_t* lengths, float* out, void* workspace, int64_t workspace_bytes);
 /* attentions.Encoder.forward (reference attentions.py:35-47). which: 0 = enc_p.encoder,
  * 1 = pitch_predictor.pitch_net, 2 = frame_prior_net.fft_block.  x [B][H][T] in, y [B][H][T] out. */
 int64_t vsp_encoder_workspace_bytes(const vsp_ctx* ctx, int B, int T);
@@ -195,6 +204,18 @@ int vsp_length_regulate(vsp_ctx* ctx, void* stream, int B, int C, int Tp, int Tf
 int64_t vsp_flow_workspace_bytes(const vsp_ctx* ctx, int B, int Tf);
 int vsp_flow_reverse(vsp_ctx* ctx, void* stream, int B, int Tf, const float* z_p, const float* g,
                      const int64_t* frame_lengths, float* z, void* workspace, int64_t workspace_bytes);
+/* One layer of modules.WN.forward (reference modules.py:148-176, dilation_rate 1; the gate is
+ * commons.fused_add_tanh_sigmoid_multiply, commons.py:100-107):
+ *   a = in_layers[layer](x) + cond_layer(g)[layer * 2h : (layer + 1) * 2h];  acts = tanh(a[:h]) * sigmoid(a[h:])
+ *   rs = res_skip_layers[layer](acts)
+ *   layer < n - 1:  x = (x + rs[:h]) * mask;  skip (+)= rs[h:]
+ *   layer == n - 1: skip = (skip (+) rs) * mask        (the `output * x_mask` of modules.py:176 is folded in)
+ * which: 0 .. n_flows-1 = flow.flows[2 * which].enc, -1 = enc_q.enc (needs the posterior-encoder weights).
+ * x [B][h][T] is updated in place; skip [B][h][T] is accumulated into when accumulate != 0, else overwritten;
+ * g [B][gin]; lengths [B]. */
+int64_t vsp_wn_layer_workspace_bytes(const vsp_ctx* ctx, int which, int B, int T);
+int vsp_wn_layer(vsp_ctx* ctx, void* stream, int which, int layer, int B, int T, float* x, const float* g,
+                 const int64_t* lengths, float* skip, int accumulate, void* workspace, int64_t workspace_bytes);
 /* Generator.forward (reference models.py:271-290). z [B][inter][T] (already masked/truncated). */
 int64_t vsp_generator_workspace_bytes(const vsp_ctx* ctx, int B, int T);
 int vsp_generator(vsp_ctx* ctx, void* stream, int B, int T, const float* z, const float* g,
@@ -244,6 +265,12 @@ int vsp_has_voice_conversion(const vsp_ctx* ctx);
  * n elements, nb bins; uw/uh [n][nb], ud [n][nb-1]; outputs y[n], logabsdet[n]. */
 int vsp_rq_spline(void* stream, int64_t n, int nb, const float* x, const float* uw, const float* uh,
                   const float* ud, int inverse, float tail_bound, float* y, float* logabsdet);
+
+/* n standard-normal draws (device, float32): element i of the Philox4x32-10 stream keyed by `seed` (counter i / 4,
+ * word i % 4, Box-Muller pairs).  A function of (seed, i) only.  This is the draw vsp_decode / vsp_infer make when
+ * their noise argument is NULL; it replaces torch.randn_like (reference models.py:718, 240) for C callers and is not
+ * bit-compatible with torch's generator. */
+int vsp_randn(void* stream, uint64_t seed, int64_t n, float* out);
 
 /* ---- mel spectrogram (reference mel_processing.py:73-112) --------------------------------- */
 /* The mel basis the reference takes from librosa.filters.mel(sampling_rate, n_fft, n_mels, fmin, fmax) with that

@@ -186,22 +186,25 @@ def length_regulate(x, duration):
     return out, lens
 
 
+def wn_layer(w, prefix: str, i: int, x, out, mask_f, gc, hidden: int, n_layers: int, kernel: int):
+    """One iteration of the loop of modules.WN.forward (reference modules.py:157-175): returns (x, out) after layer
+    ``i``; ``gc`` = cond_layer(g) (all layers' rows).  The final ``output * x_mask`` (modules.py:176) is NOT applied."""
+    a = F.conv1d(x, w[f"{prefix}.in_layers.{i}.weight"], w[f"{prefix}.in_layers.{i}.bias"], padding=(kernel - 1) // 2)
+    a = a + gc[:, i * 2 * hidden:(i + 1) * 2 * hidden]
+    acts = torch.tanh(a[:, :hidden]) * torch.sigmoid(a[:, hidden:])
+    rs = F.conv1d(acts, w[f"{prefix}.res_skip_layers.{i}.weight"], w[f"{prefix}.res_skip_layers.{i}.bias"])
+    if i < n_layers - 1:
+        return (x + rs[:, :hidden]) * mask_f, out + rs[:, hidden:]
+    return x, out + rs
+
+
 def wn(w, prefix: str, x, mask_f, g, hidden: int, n_layers: int, kernel: int):
     """modules.WN.forward with dilation_rate 1 (reference modules.py:148-176) and the fused gate
     (reference commons.py:100-107)."""
     out = torch.zeros_like(x)
     gc = F.conv1d(g, w[f"{prefix}.cond_layer.weight"], w[f"{prefix}.cond_layer.bias"])
     for i in range(n_layers):
-        a = F.conv1d(x, w[f"{prefix}.in_layers.{i}.weight"], w[f"{prefix}.in_layers.{i}.bias"],
-                     padding=(kernel - 1) // 2)
-        a = a + gc[:, i * 2 * hidden:(i + 1) * 2 * hidden]
-        acts = torch.tanh(a[:, :hidden]) * torch.sigmoid(a[:, hidden:])
-        rs = F.conv1d(acts, w[f"{prefix}.res_skip_layers.{i}.weight"], w[f"{prefix}.res_skip_layers.{i}.bias"])
-        if i < n_layers - 1:
-            x = (x + rs[:, :hidden]) * mask_f
-            out = out + rs[:, hidden:]
-        else:
-            out = out + rs
+        x, out = wn_layer(w, prefix, i, x, out, mask_f, gc, hidden, n_layers, kernel)
     return out * mask_f
 
 
@@ -496,3 +499,39 @@ def rq_spline(inputs, uw, uh, ud, inverse=False, tail_bound=5.0, min_bin_width=1
     out = torch.where(inside, out, x)
     lad = torch.where(inside, lad, torch.zeros_like(lad))
     return out, lad
+
+
+# --------------------------------------------------------------------------- the library's own normal draws
+def philox4x32_10(counter: np.ndarray, key0: int, key1: int) -> np.ndarray:
+    """Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11; the Random123
+    reference implementation's constants).  counter [n, 4] uint32 -> [n, 4] uint32.  Known answer (Random123 kat_vectors):
+    counter 0, key 0 -> 6627e8d5 e169c58d bc57ac4c 9b00dbd8."""
+    c = [counter[:, i].astype(np.uint64) for i in range(4)]
+    k0, k1 = np.uint64(key0 & 0xFFFFFFFF), np.uint64(key1 & 0xFFFFFFFF)
+    m0, m1, mask = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = m0 * c[0], m1 * c[2]
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & mask, p1 >> np.uint64(32), p1 & mask
+        c = [hi1 ^ c[1] ^ k0, lo1, hi0 ^ c[3] ^ k1, lo0]
+        k0 = (k0 + np.uint64(0x9E3779B9)) & mask
+        k1 = (k1 + np.uint64(0xBB67AE85)) & mask
+    return np.stack(c, axis=1).astype(np.uint32)
+
+
+def philox_randn(seed: int, n: int) -> np.ndarray:
+    """What ``vsp_randn(seed)`` computes (vispeech_amd/csrc/misc.hip randn_kernel): element i = Box-Muller word i % 4
+    of counter (i // 4, 0, 0, 0), key = (seed lo, seed hi); uniforms from the top 24 bits, (x + 0.5) / 2^24."""
+    groups = (n + 3) // 4
+    ctr = np.zeros((groups, 4), dtype=np.uint32)
+    q = np.arange(groups, dtype=np.uint64)
+    ctr[:, 0] = (q & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    ctr[:, 1] = (q >> np.uint64(32)).astype(np.uint32)
+    w = philox4x32_10(ctr, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    u = ((w >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+    out = np.empty((groups, 4), dtype=np.float32)
+    for p in range(2):
+        rad = np.sqrt(np.float32(-2.0) * np.log(u[:, 2 * p]))
+        ang = np.float32(6.283185307179586) * u[:, 2 * p + 1]
+        out[:, 2 * p] = rad * np.cos(ang)
+        out[:, 2 * p + 1] = rad * np.sin(ang)
+    return out.reshape(-1)[:n]

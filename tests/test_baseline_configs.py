@@ -77,6 +77,28 @@ def test_c3_full_batch_matches_oracle_on_zh_and_ja_utterances(setup):
     assert e <= WAVE_TOL
 
 
+def test_c2_full_batch_matches_oracle(setup):
+    """BASELINE config 2 (batch 16 zh utterances of ~5 s, fp32, one GPU; reference models.py:672-722): the whole batch
+    on the GPU, the longest and the shortest utterance re-computed by the oracle under the batch's padding."""
+    net, oracle, dims = setup
+    from vispeech_amd.synth import JA_RANGE, workload
+    b = workload("C2")
+    B, tf = b["phonemes"].shape[0], int(b["frame_lengths"].max())
+    assert B == 16 and b["noise"].shape == (16, dims.inter_channels, tf)
+    assert not any(JA_RANGE[0] <= b["phonemes"][i, 0] < JA_RANGE[1] for i in range(B))      # zh only
+    o, x_mask, (z, z_p, m_p, logs_p), *_ = gpu_infer(net, b, slice(0, B), tf, noise=b["noise"])
+    assert o.shape == (16, 1, 512 * tf)
+    fl = b["frame_lengths"]
+    idx = np.array([int(np.argmax(fl)), int(np.argmin(fl))])
+    ref = oracle_infer(oracle, b, idx, tf, b["noise"])
+    np.testing.assert_array_equal(x_mask.cpu().numpy()[idx], ref["x_mask"].numpy())
+    assert rel_err(z.cpu().numpy()[idx], ref["z"].numpy()) <= STAGE_TOL
+    assert rel_err(logs_p.cpu().numpy()[idx], ref["logs_p"].numpy()) <= STAGE_TOL
+    e = rel_err(o.cpu().numpy()[idx], ref["o"].numpy())
+    print("C2 full batch, longest + shortest utterance vs oracle:", e)
+    assert e <= WAVE_TOL
+
+
 def test_mixed_language_medium_batch_matches_oracle_completely(setup):
     net, oracle, dims = setup
     from vispeech_amd.synth import synth_batch

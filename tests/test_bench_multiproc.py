@@ -13,12 +13,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(*extra):
-    env = dict(os.environ, VSP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+def run_bench(*extra, gpus=2, backend="gloo"):
+    env = dict(os.environ, VSP_BENCH_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    # plain `python bench.py --gpus 2`: the parent spawns the ranks itself (what the driver runs)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", *extra]
+    # plain `python bench.py --gpus N`: the parent spawns the ranks itself (what the driver runs)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1", *extra]
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -29,6 +29,7 @@ def run_bench(*extra):
 def test_two_rank_bench_self_launches_on_one_gpu():
     d = run_bench("--batch", "4")
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["n_ranks_seen"] == 2 and "gloo" in d["collectives"]
     assert d["config"]["utterances_per_gpu"] == 4 and d["config"]["parallelism"] == "shard2" and d["config"]["global_batch"] == 8
     assert "cpu_baseline" not in d                            # timed on rank 0 at N = 1 only
     assert d["roofline"]["launches"] == 57 and d["roofline"]["attention"]["launches"] == 8
@@ -43,3 +44,14 @@ def test_c4_global_batch_is_sharded_over_the_ranks():
     b = synth_batch(**dict(WORKLOADS["C4"], batch=6))
     assert d["config"]["valid_samples_per_step"] == 512 * int(b["frame_lengths"].sum())
     assert d["config"]["padded_frames"] == int(b["frame_lengths"].max())
+
+
+def test_rccl_path_runs_on_hardware_with_one_rank():
+    """the nccl (= RCCL) branch of bench.py -- init_process_group("nccl", device_id=...), the broadcast
+    of the packed weight arena, the frame-count all-reduce, the side-stream waveform gather with persistent buffers,
+    the barriers -- executed on the MI355X.  One rank (this box has one GPU; RCCL refuses two ranks per device),
+    launched through the self-launch path: the parent never touches the GPU, the rank is a fresh child process."""
+    d = run_bench("--dist", "--batch", "4", "--no-cpu-baseline", gpus=1, backend="nccl")
+    assert d["n_gpus"] == 1 and d["n_ranks_seen"] == 1 and "nccl" in d["collectives"]
+    assert d["value"] > 0 and d["config"]["utterances_per_gpu"] == 4
+    assert d["roofline"]["launches"] == 57

@@ -53,6 +53,35 @@ class _FakeNet:
         return (o, x_mask, None, None, None, None)
 
 
+def test_a_stream_that_is_never_started_does_not_keep_the_lock():
+    """stream() takes the single-flight lock before the first chunk exists; a caller that drops or closes
+    the stream without ever advancing it must still release it (a bare generator would never run its finally)."""
+    import gc
+    from vispeech_amd.service import Busy, SynthesisService
+    svc = SynthesisService(_FakeNet())
+    batch = dict(phonemes=np.zeros((2, 3), np.int64), lengths=np.array([3, 3]), sid=np.array([0, 1]))
+    it = svc.stream(batch)
+    assert svc.busy
+    with pytest.raises(Busy):
+        svc.stream(batch)
+    del it                                   # never advanced
+    gc.collect()
+    assert not svc.busy
+    it = svc.stream(batch)
+    it.close()
+    it.close()                               # idempotent
+    assert not svc.busy
+    assert list(it) == []                    # a closed stream yields nothing and does not touch the lock again
+    with svc.stream(batch) as it2:
+        assert svc.busy
+    assert not svc.busy
+    # a stream whose first chunk fails (the fake net has no engine) releases the lock too
+    it = svc.stream(batch)
+    with pytest.raises(AttributeError):
+        next(it)
+    assert not svc.busy
+
+
 def test_service_is_single_flight_and_never_queues():
     """reference inference_api.py:13, 37: mutex.acquire(blocking=False) -- a second request is refused at once."""
     from vispeech_amd.service import Busy, SynthesisService, pcm16

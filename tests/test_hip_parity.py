@@ -362,10 +362,19 @@ def test_abi_error_paths_on_device(net):
     assert rc == -1
     with pytest.raises(ValueError):
         net.infer(torch.zeros(1, 3, dtype=torch.int64), torch.tensor([3]), sid=None)
-    with pytest.raises(_lib.VspError):
-        enc = eng.encode(torch.ones(1, 3, dtype=torch.int64), torch.tensor([3]), torch.tensor([1]),
-                         duration_ctl=torch.ones(1, 3), pitch_ctl=torch.ones(1, 3), energy_ctl=torch.ones(1, 3))
-        eng.decode(enc, 3, None, 0.5)          # noise required when noise_scale != 0
+    enc = eng.encode(torch.ones(1, 3, dtype=torch.int64), torch.tensor([3]), torch.tensor([1]),
+                     duration_ctl=torch.ones(1, 3), pitch_ctl=torch.ones(1, 3), energy_ctl=torch.ones(1, 3))
+    with pytest.raises(ValueError):
+        eng.decode(enc, 3, None, 0.5, max_len=-1)          # the C side reads max_len < 0 as "no limit": refused here
+    # vsp_attention: caller-owned workspace (ABI 4), too small -> error code
+    qkv = torch.zeros(1, 3 * 192, 16, device=net.device)
+    ln = torch.tensor([16], device=net.device)
+    out = torch.zeros(1, 192, 16, device=net.device)
+    rc = eng.lib.vsp_attention(eng.ctx, None, 0, 0, 1, 16, P(qkv), P(ln), P(out), P(ws), 16)
+    assert rc == -6
+    assert eng.lib.vsp_attention_workspace_bytes(eng.ctx, 1, 16) > 16
+    rc = eng.lib.vsp_wn_layer(eng.ctx, None, 99, 0, 1, 16, P(out), P(g), P(ln), P(qkv), 0, P(ws), ws.numel())
+    assert rc == -1
 
 
 def test_reduced_precision_mode_is_opt_in_and_gated(dims, weights, golden_dir, monkeypatch):
@@ -393,15 +402,13 @@ def test_reduced_precision_mode_is_opt_in_and_gated(dims, weights, golden_dir, m
     assert e > 1e-5          # i.e. really the reduced-precision path
 
 
-@pytest.mark.parametrize("env", [{"VSP_FUSE_PAIRS": "0"}, {"VSP_CHAIN": "0"}, {"VSP_CHAIN": "7", "VSP_CHAIN_CH": "64"},
-                                 {"VSP_CHAIN_WAVES": "4"}, {"VSP_CHAIN_WAVES": "8"}, {"VSP_CHAIN128": "7"}],
-                         ids=["two_launches", "pair_launches", "chains_64ch_too", "chains_256col", "chains_512col",
-                              "pairs_128ch_fused"])
+@pytest.mark.parametrize("env", [{"VSP_FUSE_PAIRS": "0"}, {"VSP_CHAIN": "0"}, {"VSP_CHAIN": "7"}],
+                         ids=["two_launches", "pair_launches", "chains_for_every_kernel_size"])
 def test_fused_resblock_paths_are_bit_identical(net, dims, weights, monkeypatch, env):
     """The ResBlocks of the 32/64-channel stages run fused (gen16.hip): by default a whole ResBlock of the
     32-channel stage is ONE launch (g16_chain: the running x in registers, every intermediate in LDS, the chain's halo
     recomputed per tile) and a conv pair of the 64-channel stage is one launch (g16_pair).  VSP_CHAIN=0 runs pairs
-    everywhere, VSP_FUSE_PAIRS=0 one g16_conv launch per convolution, VSP_CHAIN_CH=64 chains on both stages.  Same
+    everywhere, VSP_FUSE_PAIRS=0 one g16_conv launch per convolution, VSP_CHAIN=7 chains for k3, k7 and k11.  Same
     split products, same accumulation order => identical bits, for tiles that start/end anywhere in the utterance."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -421,10 +428,9 @@ def test_fused_resblock_paths_are_bit_identical(net, dims, weights, monkeypatch,
 
 def test_alternative_kernel_paths_match_golden(dims, weights, golden_dir, monkeypatch):
     """Switchable second implementations stay correct: frame-rate convs on the f32 matrix core
-    (VSP_FRAME=f32) and attention with the key range split inside the block for every launch
-    (VSP_ATT_KSPLIT=1; normally only long single utterances take that path)."""
+    (VSP_FRAME=f32) and the two-pass f32 attention kernel (VSP_ATT=f32)."""
     monkeypatch.setenv("VSP_FRAME", "f32")
-    monkeypatch.setenv("VSP_ATT_KSPLIT", "1")
+    monkeypatch.setenv("VSP_ATT", "f32")
     from vispeech_amd import config as vcfg
     from vispeech_amd.models import SynthesizerTrn
     args, kwargs = vcfg.synthesizer_args(vcfg.default_hparams())
@@ -483,3 +489,72 @@ def test_attention_stage_matches_oracle(net, weights, dims, T, lens):
         # zeroed by the encoder's final x * mask)
         for b, n in enumerate(lens):
             assert rel_err(to_np(out)[b, :, :n], ref.numpy()[b, :, :n]) <= STAGE_TOL, (T, which, b)
+
+
+@pytest.mark.parametrize("which,T,lens", [(1, 37, [37, 20, 1]), (3, 130, [130, 64])])
+def test_wn_layer_matches_oracle(net, oracle, dims, which, T, lens):
+    """vsp_wn_layer (SURVEY 8b's per-stage entry; reference modules.py:148-176): the four layers of a coupling
+    layer's WN one call at a time, running x and the skip sum compared with the oracle after EVERY layer (ragged
+    masks, odd T)."""
+    import torch.nn.functional as F
+    from oracle.vispeech_oracle import wn_layer
+    r = np.random.Generator(np.random.PCG64(100 * which + T))
+    B, h, nl = len(lens), dims.hidden_channels, dims.flow_layers
+    x0 = r.standard_normal((B, h, T)).astype(np.float32)
+    g = r.standard_normal((B, dims.gin_channels)).astype(np.float32)
+    lens_a = np.array(lens, dtype=np.int64)
+    mask = (torch.arange(T)[None, :] < torch.from_numpy(lens_a)[:, None]).to(torch.float32)[:, None, :]
+    w, prefix = oracle.w, f"flow.flows.{2 * which}.enc"
+    gc = F.conv1d(torch.from_numpy(g)[:, :, None], w[f"{prefix}.cond_layer.weight"], w[f"{prefix}.cond_layer.bias"])
+    xr = torch.from_numpy(x0) * mask
+    outr = torch.zeros_like(xr)
+    xg, skg = (torch.from_numpy(x0) * mask).to(net.device), None
+    for i in range(nl):
+        xr, outr = wn_layer(w, prefix, i, xr, outr, mask, gc, h, nl, dims.flow_kernel)
+        xg, skg = net._engine.wn_layer(which, i, xg, g, lens_a, skg)
+        expect_skip = outr * mask if i == nl - 1 else outr          # the last layer folds WN's `output * x_mask` in
+        assert rel_err(to_np(xg), xr.numpy()) <= STAGE_TOL, (which, i)
+        assert rel_err(to_np(skg), expect_skip.numpy()) <= STAGE_TOL, (which, i)
+
+
+def test_library_noise_draw_is_the_documented_philox_stream(net, oracle, dims):
+    """noise == NULL: the library draws the reparameterisation noise itself (vsp_randn: Philox4x32-10 + Box-Muller,
+    include/vispeech_hip.h) -- the C caller's torch.randn_like (reference models.py:718).  Checked against the numpy
+    restatement in oracle/, for moments, for determinism, and end to end: infer(noise_seed=s) == infer(noise=randn(s))."""
+    from oracle.vispeech_oracle import philox_randn
+    eng = net._engine
+    n = 3 * 192 * 77 + 1                                   # not a multiple of four
+    got = to_np(eng.randn(0x1234567890ABCDEF, n))
+    ref = philox_randn(0x1234567890ABCDEF, n)
+    assert np.abs(got - ref).max() <= 2e-5                 # same words; logf / sincosf differ in the last ulps
+    big = to_np(eng.randn(7, 1 << 22))
+    assert abs(big.mean()) < 3e-3 and abs(big.std() - 1.0) < 3e-3 and np.isfinite(big).all()
+    assert abs(float(np.mean(big ** 3))) < 1e-2 and abs(float(np.mean(big ** 4)) - 3.0) < 3e-2
+    assert not np.array_equal(got[:64], to_np(eng.randn(8, 64)))
+    from vispeech_amd.synth import synth_batch
+    b = synth_batch(2, seed=11, mean_phonemes=8, std_phonemes=1, min_phonemes=6, max_phonemes=10, mean_frames=30, jitter_frames=5)
+    t = lambda a: torch.from_numpy(np.asarray(a)).to(net.device)
+    kw = dict(sid=t(b["sid"]), noise_scale=0.667, duration_control=t(b["duration"]), pitch_control=t(b["f0"]),
+              energy_control=t(b["energy"]))
+    a = net.infer(t(b["phonemes"]), t(b["lengths"]), noise_seed=42, **kw)
+    tf = a[2][0].shape[2]
+    drawn = eng.randn(42, 2, dims.inter_channels, tf)
+    c = net.infer(t(b["phonemes"]), t(b["lengths"]), noise=drawn, **kw)
+    assert torch.equal(a[0], c[0]) and torch.equal(a[2][1], c[2][1])
+    d = net.infer(t(b["phonemes"]), t(b["lengths"]), noise_seed=43, **kw)
+    assert not torch.equal(a[2][1], d[2][1])
+    ref = oracle.infer(b["phonemes"], b["lengths"], b["sid"], noise=to_np(drawn), noise_scale=0.667,
+                       duration_control=b["duration"], pitch_control=b["f0"], energy_control=b["energy"])
+    assert rel_err(to_np(a[0]), ref["o"].numpy()) <= WAVE_TOL
+
+
+def test_attention_operands_beyond_the_f16_range_stay_finite(net, dims):
+    """the split-f16 attention packs q / k / v with fixed scales; magnitudes beyond the f16 range are clamped
+    (documented in include/vispeech_hip.h) instead of turning rows into NaN."""
+    T, H = 40, dims.hidden_channels
+    qkv = np.random.Generator(np.random.PCG64(9)).standard_normal((1, 3 * H, T)).astype(np.float32)
+    qkv[0, 5, 7] = 1e6
+    qkv[0, H + 9, 3] = -1e7
+    qkv[0, 2 * H + 1, 11] = 3e5
+    out = to_np(net._engine.attention(0, 0, qkv, np.array([T])))
+    assert np.isfinite(out).all()

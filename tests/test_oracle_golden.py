@@ -118,3 +118,16 @@ def test_oracle_mel_filterbank_properties():
     m = mel_spectrogram(y, 44100, 2048, 512, 80).numpy()
     assert m.shape == (1, 80, 16) and np.isfinite(m).all()
     assert abs(int(m[0, :, 8].argmax()) - int(np.abs(fb[:, round(440.0 / df)]).argmax())) <= 1
+
+
+def test_philox_restatement_known_answers():
+    """The oracle's restatement of the library's noise stream (vsp_randn) is pinned on the Random123 known-answer
+    vectors of Philox4x32-10 (kat_vectors: counter / key all zero, all ones)."""
+    from oracle.vispeech_oracle import philox4x32_10, philox_randn
+    z = philox4x32_10(np.zeros((1, 4), np.uint32), 0, 0)[0]
+    assert [int(x) for x in z] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    f = philox4x32_10(np.full((1, 4), 0xFFFFFFFF, np.uint32), 0xFFFFFFFF, 0xFFFFFFFF)[0]
+    assert [int(x) for x in f] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    x = philox_randn(99, 200001)
+    assert x.shape == (200001,) and abs(float(x.mean())) < 1e-2 and abs(float(x.std()) - 1) < 1e-2
+    np.testing.assert_array_equal(x[:1000], philox_randn(99, 1000))      # a function of (seed, index) only

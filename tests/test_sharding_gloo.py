@@ -73,7 +73,7 @@ def _worker(rank, world, port, q):
         torch.set_num_threads(2)
         from oracle.vispeech_oracle import Oracle
         from vispeech_amd.schema import ModelDims
-        from vispeech_amd.sharding import broadcast_weights, gather_batch, global_max, infer_sharded
+        from vispeech_amd.sharding import BatchGatherer, broadcast_weights, gather_batch, global_max, infer_sharded, shard_counts
         from vispeech_amd.synth import synth_batch, synth_state_dict
         # 1. collectives
         assert global_max(10 + 5 * rank, "cpu") == 10 + 5 * (world - 1)
@@ -87,6 +87,25 @@ def _worker(rank, world, port, q):
             assert all(float(s.mean()) == r for r, s in enumerate(shards))
         else:
             assert shards is None
+        # persistent gatherer: sizes from shard_range (no exchange), buffers reused over steps, one gather in flight
+        counts = shard_counts(5, world)
+        assert counts == [3, 2]
+        gth = BatchGatherer(counts, (1, 4), torch.float32, "cpu", dst=0)
+        bufs = None
+        for step in range(3):
+            gth.start(torch.full((counts[rank], 1, 4), float(10 * step + rank)))
+            got = gth.wait()
+            if rank == 0:
+                assert [tuple(s.shape) for s in got] == [(3, 1, 4), (2, 1, 4)]
+                assert [float(s.mean()) for s in got] == [10.0 * step, 10.0 * step + 1]
+                ptrs = [s.data_ptr() for s in got]
+                assert bufs is None or bufs == ptrs          # the same receive buffers every step
+                bufs = ptrs
+            else:
+                assert got is None
+        with pytest.raises(ValueError):
+            gth.start(torch.zeros(counts[rank] + 1, 1, 4))
+        assert gather_batch(torch.zeros(counts[rank], 1, 4), dst=0, counts=counts) is None or rank == 0
         # 2. sharded infer == unsharded infer
         dims = ModelDims()
         sd = synth_state_dict(dims, seed=1234, infer_only=True)

@@ -4,8 +4,10 @@ WRITE_SIZE collected separately, as MI355X_MICROARCH.md prescribes: FETCH_SIZE t
 slots, WRITE_SIZE 2).  Units are KiB; on gfx950 FETCH_SIZE reports exactly half of the bytes of a
 wide (16 B/lane) coalesced streaming read, so the read side is doubled; WRITE_SIZE is taken as is.
 usage: traffic_from_pmc.py <kernel substr[|substr...]> <fetch counter_collection.csv> <write counter_collection.csv> <generator> <utterances> [padded_frames] [kernels tag] [steps in the pmc run]"""
-import csv, json, sys
+import csv, hashlib, json, os, sys
 sub, fcsv, wcsv, gen, utt = sys.argv[1:6]
+LIB = os.environ.get("VSP_LIB_PATH") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vispeech_amd", "lib", "libvispeech_hip.so")
+lib_sha = hashlib.sha256(open(LIB, "rb").read()).hexdigest()   # bench.py reports these bytes only for THIS library build
 frames = int(sys.argv[6]) if len(sys.argv) > 6 else 489
 steps = int(sys.argv[8]) if len(sys.argv) > 8 else 2   # bench.py --steps 1 --warmup 1 --profile-steps 0
 ktag = sys.argv[7] if len(sys.argv) > 7 else 'g16c1'   # g16 kernels, ResBlock chains per VSP_CHAIN=1 (the default)
@@ -19,7 +21,7 @@ f, nf = total(fcsv, 'FETCH_SIZE')
 w, nw = total(wcsv, 'WRITE_SIZE')
 assert nf == nw and nf > 0, (nf, nw)
 fetch_b, write_b = 2.0 * f * 1024.0, w * 1024.0
-out = {"kernel": sub, "kernels": ktag, "generator": gen, "utterances": int(utt), "padded_frames": frames, "launches": nf, "launches_per_step": nf / steps,
+out = {"kernel": sub, "kernels": ktag, "lib_sha256": lib_sha, "generator": gen, "utterances": int(utt), "padded_frames": frames, "launches": nf, "launches_per_step": nf / steps,
        "fetch_bytes_per_launch": fetch_b / nf, "write_bytes_per_launch": write_b / nf,
        "hbm_bytes_per_launch": (fetch_b + write_b) / nf,
        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), KiB units, FETCH_SIZE x2 (gfx950 "

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VSP_LIB_PATH") or os.path.join(_HERE, "lib", "libvispeech_hip.so")
 
 VSP_MAX_LIST = 8
-ABI_VERSION = 3
+ABI_VERSION = 4
 DTYPES = {"float32": 0, "float16": 1, "bfloat16": 2, "float64": 3}   # VSP_DTYPE_*
 PROF_GENERATOR, PROF_ATTENTION, PROF_FRAME = 0, 1, 2
 
@@ -43,6 +43,7 @@ _P = C.c_void_p
 _I = C.c_int
 _I64 = C.c_int64
 _F = C.c_float
+_U64 = C.c_uint64
 
 # name -> (restype, argtypes); every symbol include/vispeech_hip.h declares
 SIGNATURES = {
@@ -63,11 +64,15 @@ SIGNATURES = {
     "vsp_encode": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _I64]),
     "vsp_frame_lengths_host": (_I, [_P, _P, _I, _P, C.POINTER(_I64), C.POINTER(_I64)]),
     "vsp_decode_workspace_bytes": (_I64, [_P, _I, _I, _I]),
-    "vsp_decode": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _I64]),
+    "vsp_decode": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _U64, _F, _P, _P, _P, _P, _P, _P, _P, _I64]),
     "vsp_infer_workspace_bytes": (_I64, [_P, _I, _I, _I]),
-    "vsp_infer": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _F, _F, _P, _F,
+    "vsp_infer": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _F, _F, _P, _U64, _F,
                        _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64]),
-    "vsp_attention": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "vsp_attention_workspace_bytes": (_I64, [_P, _I, _I]),
+    "vsp_attention": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I64]),
+    "vsp_wn_layer_workspace_bytes": (_I64, [_P, _I, _I, _I]),
+    "vsp_wn_layer": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I64]),
+    "vsp_randn": (_I, [_P, _U64, _I64, _P]),
     "vsp_encoder_workspace_bytes": (_I64, [_P, _I, _I]),
     "vsp_encoder": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _I64]),
     "vsp_length_regulate": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),

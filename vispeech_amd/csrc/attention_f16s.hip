@@ -46,7 +46,12 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 // value the residual is taken against: left to itself hipcc re-derived hi for the subtraction by another conversion
 // path that rounds ties differently, which put single elements off by a whole f16 ulp (one q element in ~10^4:
 // found as 3e-5 errors in single query rows of the T = 300 parity case).
+// Operands beyond the f16 range are clamped to its largest finite value (a scaled |q| > 6.5e4 is |q| > ~3.4e3 before
+// scaling; the reference's layer-normed activations are O(1..10)): the result stays finite instead of turning the
+// whole row into NaN through inf - inf; the fp32 kernel (VSP_ATT=f32) has no such limit (include/vispeech_hip.h).
 __device__ __forceinline__ void af_split2(f32x2 x, f16x2& h, f16x2& l) {
+  x.x = __builtin_amdgcn_fmed3f(x.x, -65504.f, 65504.f);
+  x.y = __builtin_amdgcn_fmed3f(x.y, -65504.f, 65504.f);
   h = __builtin_convertvector(x, f16x2);
   asm volatile("" : "+v"(h));
   const f32x2 back = __builtin_convertvector(h, f32x2);

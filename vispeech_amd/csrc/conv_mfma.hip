@@ -706,9 +706,14 @@ hipError_t launch_conv(const ConvArgs& a, int B, hipStream_t s) {
       (a.split_row && (a.ups_s > 0 || a.act == 2 || !a.out2)))
     return hipErrorInvalidValue;
   const bool gate = a.act == 2;
-  static int ring = -1;   // VSP_FRAME_RING=0: weights from global memory into registers (the round-1 form of these kernels)
+  // (ring = 0: weights from global memory into registers, the round-1 form of these kernels; an experiment knob)
+#ifdef VSP_EXPERIMENTS
+  static int ring = -1;
   if (ring < 0) { const char* e = getenv("VSP_FRAME_RING"); ring = e ? atoi(e) != 0 : 1; }
-  if (a.f16s && ring) {
+#else
+  constexpr bool ring = true;
+#endif
+  if (ring && a.f16s) {
     if (a.ups_s > 0) return hipErrorInvalidValue;
     if (a.M <= 32 && !gate) {
       if (a.Nq >= 1024) return launch_tile<1, 4, 1, 4, true, true>(a, B, s);
@@ -717,9 +722,13 @@ hipError_t launch_conv(const ConvArgs& a, int B, hipStream_t s) {
     if (a.Nq <= 96) return launch_tile<2, 1, 1, 2, true, true>(a, B, s);
     // M % 128 == 0: 128-row x 128-column tiles (two blocks per CU) for long time axes; utterance-sized ones take the
     // 64-row tile -- twice the blocks at three per CU fill the chip's rounds better than the halved window reuse
-    // costs (C3 -0.15 ms, one utterance -11 %; the 5168-frame utterance +4 % if it did).  VSP_FRAME_TILE=128|64 forces one.
+    // costs (C3 -0.15 ms, one utterance -11 %; the 5168-frame utterance +4 % if it did).
+#ifdef VSP_EXPERIMENTS
     static int force_rows = -1;
     if (force_rows < 0) { const char* e = getenv("VSP_FRAME_TILE"); force_rows = e ? atoi(e) : 0; }
+#else
+    constexpr int force_rows = 0;
+#endif
     const bool wide = force_rows ? force_rows == 128 : a.Nq >= 1024;
     if (a.M <= 64 || (a.M % 128 != 0 && a.M < 256) || !wide) {
       if (a.Nq >= 1024) return launch_tile<2, 2, 1, 4, true, true>(a, B, s);

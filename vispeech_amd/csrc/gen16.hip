@@ -503,12 +503,15 @@ hipError_t launch_g16_conv(const ClConvArgs& a, int B, hipStream_t s) {
   }
   // Row tile: 128 rows x 256 columns (one block per CU) when that fills the chip; a launch with fewer blocks than CUs
   // (one or two utterances: the 256 / 128-channel stages) takes the 64- or 32-row tile and spreads over 2-4x the CUs.
-  // VSP_G16_ROWS=128|64|32 forces one.
-  static int force = -1, fill = 200;
+#ifdef VSP_EXPERIMENTS
+  static int force = -1, fill = 200;   // VSP_G16_ROWS=128|64|32 forces a row tile
   if (force < 0) {
     const char* e = getenv("VSP_G16_ROWS"); force = e ? atoi(e) : 0;
     if (const char* f = getenv("VSP_G16_FILL")) fill = atoi(f);
   }
+#else
+  constexpr int force = 0, fill = 200;
+#endif
   const long col_tiles = (long)((a.Nq + 255) / 256) * B;
   int want = 128;
   if (force) want = force;
@@ -804,14 +807,22 @@ hipError_t launch_g16_pair(const ClPairArgs& a, int B, hipStream_t s) {
   if (!g16_pair_supported(a.C, a.K, a.dil) || a.T <= 0 || B <= 0 || (a.x_bs & 3) || (a.o_bs & 3) ||
       (reinterpret_cast<uintptr_t>(a.x) & 15) || (reinterpret_cast<uintptr_t>(a.out) & 15) || a.x == a.out)
     return hipErrorInvalidValue;
-  // block shape: 16 waves x 32 columns (one block per CU: ONE weight ring per CU, half the LDS-DMA pieces and L2
-  // reads of two 8-wave blocks) or 8 waves (two blocks per CU); VSP_PAIR_WAVES=8 selects the latter
+  // block shape: 8 waves x 32 columns, two blocks per CU (the 16-wave one-block-per-CU form -- one weight ring per CU,
+  // half the LDS-DMA pieces -- measured 12 % slower: profiles/r02_same_box_ab.txt; experiment builds keep it)
+#ifdef VSP_EXPERIMENTS
   static int nwv = -1;
   if (nwv < 0) { const char* e = getenv("VSP_PAIR_WAVES"); nwv = e ? atoi(e) : 8; }
+#else
+  constexpr int nwv = 8;
+#endif
   if (a.terms == 1)
     return a.C == 32 ? launch_g16_pair_tile<1, 2, 1, 8>(a, B, s) : launch_g16_pair_tile<2, 1, 1, 8>(a, B, s);
   if (nwv == 8) return a.C == 32 ? launch_g16_pair_tile<1, 2, 3, 8>(a, B, s) : launch_g16_pair_tile<2, 1, 3, 8>(a, B, s);
+#ifdef VSP_EXPERIMENTS
   return a.C == 32 ? launch_g16_pair_tile<1, 2, 3, 16>(a, B, s) : launch_g16_pair_tile<2, 1, 3, 16>(a, B, s);
+#else
+  return hipErrorInvalidValue;
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1142,9 +1153,13 @@ hipError_t launch_g16_chain(const ClChainArgs& a0, int B, hipStream_t s) {
   a.halo = g16_chain_halo(a.K, a.dil, a.np);
   // few, fat waves (64 columns x all channels each, up to 256 registers).  32 channels: one 8-wave block of 512
   // columns per CU when the halo would eat more than a quarter of a 256-column tile, else two 4-wave blocks of 256
-  // columns (their convolution hand-offs overlap); VSP_CHAIN_WAVES=4|8 forces one shape
-  static int force = -1;
+  // columns (their convolution hand-offs overlap)
+#ifdef VSP_EXPERIMENTS
+  static int force = -1;                 // VSP_CHAIN_WAVES=4|8 forces one shape
   if (force < 0) { const char* e = getenv("VSP_CHAIN_WAVES"); force = e ? atoi(e) : 0; }
+#else
+  constexpr int force = 0;
+#endif
   const bool wide = a.C == 32 && (force ? force == 8 : 2 * a.halo > 64);
   // <NCH, NW, G, TERMS, NWV>
   if (a.C == 128) return a.terms == 1 ? launch_g16_chain_tile<4, 1, 1, 1, 8>(a, B, s) : launch_g16_chain_tile<4, 1, 1, 3, 8>(a, B, s);

@@ -363,6 +363,51 @@ hipError_t launch_reparam(const float* m_p, const float* logs_p, const float* no
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// Standard-normal draws for callers without a generator of their own (the torch.randn_like of reference
+// models.py:718 / :240): Philox4x32-10 (Salmon et al., SC'11; key = seed lo | hi, counter = (i / 4, 0, 0, 0)) ->
+// four 32-bit words -> two Box-Muller pairs, element i = word i % 4 of counter i / 4.  A function of (seed, i) only:
+// the same seed gives the same tensor on any grid and any GPU.  NOT torch's generator: a torch.manual_seed(s) draw
+// is a different sequence (documented in include/vispeech_hip.h).
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__global__ void __launch_bounds__(256) randn_kernel(uint32_t k0, uint32_t k1, long n, float* __restrict__ out) {
+  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;   // counter = group of four elements
+  if (4 * q >= n) return;
+  uint32_t w[4];
+  philox4x32_10((uint32_t)(q & 0xffffffffu), (uint32_t)((unsigned long)q >> 32), 0u, 0u, k0, k1, w);
+  float v[4];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const float u1 = ((float)(w[2 * p] >> 8) + 0.5f) * (1.f / 16777216.f);      // (0, 1): 24 bits, never 0
+    const float u2 = ((float)(w[2 * p + 1] >> 8) + 0.5f) * (1.f / 16777216.f);
+    const float rad = sqrtf(-2.f * logf(u1));
+    float sn, cs;
+    sincosf(6.283185307179586f * u2, &sn, &cs);
+    v[2 * p] = rad * cs;
+    v[2 * p + 1] = rad * sn;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (4 * q + j < n) out[4 * q + j] = v[j];
+}
+hipError_t launch_randn(uint64_t seed, long n, float* out, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(randn_kernel, dim3(cdiv((n + 3) / 4, 256)), dim3(256), 0, s, (uint32_t)(seed & 0xffffffffu),
+                     (uint32_t)(seed >> 32), n, out);
+  return hipGetLastError();
+}
+
 __global__ void mask_u8_kernel(const int64_t* __restrict__ lengths, uint8_t* __restrict__ mask, int T) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
   if (t >= T) return;

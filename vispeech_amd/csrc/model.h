@@ -117,8 +117,6 @@ struct vsp_ctx {
                      // 2: same kernels with plain f16 operands (VSP_GENERATOR=f16, opt-in reduced precision)
   bool frame_f16s = true;  // frame/phoneme-rate convs on the split-f16 matrix path (VSP_FRAME=f32: f32 MFMA)
   bool att_f16s = true;    // attention on the split-f16 matrix path, one pass (VSP_ATT=f32: the two-pass f32 MFMA kernel)
-  void* att_scratch = nullptr;   // packed operand images for the vsp_attention unit entry (grown on demand; the infer
-  size_t att_scratch_bytes = 0;  // path takes them from the caller's workspace)
   int att_ksplit = -1;     // attention key-split blocks: -1 automatic (under-filled grids), 0 never, 1 always (VSP_ATT_KSPLIT)
   int chain_mask = 0x1;    // ResBlock chains (all dilation pairs of a ResBlock in one launch): bit 0 = k3, 1 = k7, 2 = k11 (VSP_CHAIN=<mask>; measured: only k3 pays)
   int chain128_mask = 0;   // conv PAIRS of the 128-channel stage as one launch each (g16_chain, one pair): bit 0 = k3, 1 = k7, 2 = k11 (VSP_CHAIN128)

@@ -282,13 +282,10 @@ int plan_model(vsp_ctx* ctx) {
     Q.proj_m = p.conv(inter, h, 1, 1, 0, true);
     Q.proj_s = p.conv(inter, h, 1, 1, 0, true);
   }
-  // generator (its channel-major f32 form is the second implementation kept for VSP_GENERATOR=f32)
-  // (conv_pre and the speaker conditioning run on the split-f16 path whenever the vocoder does)
-  p.f16s = ctx->frame_f16s && ctx->gen_mode != 0;
+  // generator (its channel-major f32 form is the second implementation kept for VSP_GENERATOR=f32).
+  // ctx->gen_mode holds the requested mode here (vsp_create parses VSP_GENERATOR before planning); it falls back to 0
+  // when the split-f16 channels-last kernels do not cover the configuration, BEFORE conv_pre / cond are planned.
   const int c0 = c.upsample_initial_channel;
-  m.g_pre = p.conv(c0, inter, 7, 1, 3, true);
-  m.g_cond = p.conv(c0, gin, 1, 1, 0, true);
-  p.f16s = false;
   int ch = c0;
   // the split-f16 channels-last generator covers channel counts of 32 or multiples of 64
   m.has_cl = true;
@@ -298,6 +295,11 @@ int plan_model(vsp_ctx* ctx) {
   }
   if ((c0 >> c.n_upsamples) > 64) m.has_cl = false;  // conv_post_cl covers <= 64 channels
   if (!m.has_cl) ctx->gen_mode = 0;
+  // (conv_pre and the speaker conditioning run on the split-f16 path whenever the vocoder does)
+  p.f16s = ctx->frame_f16s && ctx->gen_mode != 0;
+  m.g_pre = p.conv(c0, inter, 7, 1, 3, true);
+  m.g_cond = p.conv(c0, gin, 1, 1, 0, true);
+  p.f16s = false;
   for (int i = 0; i < c.n_upsamples; ++i) {
     const int s = c.upsample_rates[i], k = c.upsample_kernel_sizes[i];
     if (s < 1 || k % s || (k - s) % 2)

@@ -61,11 +61,13 @@ class Engine:
         for k, v in state_dict.items():
             if torch.is_tensor(v) and str(v.dtype).replace("torch.", "") in _lib.DTYPES and (v.is_cuda or v.dtype != torch.float32):
                 t = v.detach().contiguous()
+                if t.is_cuda:
+                    # the library copies with a blocking hipMemcpy on the NULL stream, which does not order against
+                    # torch's (possibly non-blocking) streams: whatever produced `t` must have finished first
+                    torch.cuda.synchronize(t.device)
                 shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
                 rc = self.lib.vsp_set_weight_typed(self.ctx, k.encode(), C.c_void_p(t.data_ptr()), shape, t.dim(),
                                                    _lib.DTYPES[str(t.dtype).replace("torch.", "")], int(t.is_cuda))
-                if t.is_cuda:
-                    torch.cuda.synchronize(t.device)
                 if rc == -4:
                     unexpected.append(k)
                     continue
@@ -177,11 +179,14 @@ class Engine:
         return list(host), int(mx.value)
 
     def decode(self, enc: Mapping[str, torch.Tensor], Tf: int, noise: Optional[torch.Tensor], noise_scale: float,
-               max_len: Optional[int] = None) -> Dict[str, torch.Tensor]:
+               max_len: Optional[int] = None, noise_seed: int = 0) -> Dict[str, torch.Tensor]:
+        """``noise`` None with ``noise_scale`` != 0: the library draws it on the device (``vsp_randn(noise_seed)``)."""
         d = self.dims
         B, _, Tp = enc["x_var"].shape
         inter = d.inter_channels
-        Tdec = Tf if max_len is None else max(min(Tf, int(max_len)), 0)
+        if max_len is not None and int(max_len) < 0:
+            raise ValueError("max_len must be >= 0 (None = no truncation)")   # the C side reads < 0 as "no limit"
+        Tdec = Tf if max_len is None else min(Tf, int(max_len))
         if noise is not None:
             noise = _dev_f32(noise, self.device)
             if tuple(noise.shape) != (B, inter, Tf):
@@ -193,9 +198,10 @@ class Engine:
                    logs_p=self._f(B, inter, Tf))
         ws = self._workspace("decode", self.lib.vsp_decode_workspace_bytes(self.ctx, B, Tp, Tf))
         with torch.cuda.device(self.device):
-            rc = self.lib.vsp_decode(self.ctx, self._stream(), B, Tp, Tf, -1 if max_len is None else int(max_len),
+            rc = self.lib.vsp_decode(self.ctx, self._stream(), B, Tp, Tf, -1 if max_len is None else Tdec,
                                      _ptr(enc["x_var"]), _ptr(enc["g"]), _ptr(enc["cum_dur"]),
-                                     _ptr(enc["frame_lengths"]), _ptr(noise), float(noise_scale), _ptr(o_buf),
+                                     _ptr(enc["frame_lengths"]), _ptr(noise), int(noise_seed) & (2**64 - 1),
+                                     float(noise_scale), _ptr(o_buf),
                                      _ptr(out["x_mask"]), _ptr(out["z"]), _ptr(out["z_p"]), _ptr(out["m_p"]),
                                      _ptr(out["logs_p"]), _ptr(ws), ws.numel())
         _lib.check(rc, self.ctx, "vsp_decode")
@@ -205,7 +211,7 @@ class Engine:
     # ------------------------------------------------------------------ per-stage entry points
     def infer_padded(self, phonemes, lengths, sid, tf_pad: int, noise, noise_scale: float = 1.0, max_len=None,
                      duration_ctl=None, pitch_ctl=None, energy_ctl=None, duration_scale: float = 1.0,
-                     pitch_scale: float = 1.0, energy_scale: float = 1.0) -> Dict[str, torch.Tensor]:
+                     pitch_scale: float = 1.0, energy_scale: float = 1.0, noise_seed: int = 0) -> Dict[str, torch.Tensor]:
         """``vsp_infer``: the whole path in ONE call and without the host read of the frame counts, for
         callers that know an upper bound ``tf_pad`` of the frame count (supplied durations / fixed max_len)."""
         ph = _dev_i64(phonemes, self.device)
@@ -213,6 +219,8 @@ class Engine:
         ln, sd = _dev_i64(lengths, self.device), _dev_i64(sid, self.device)
         ctl = [None if t is None else _dev_f32(t, self.device).reshape(B, Tp) for t in (duration_ctl, pitch_ctl, energy_ctl)]
         Tf = int(tf_pad)
+        if max_len is not None and int(max_len) < 0:
+            raise ValueError("max_len must be >= 0 (None = no truncation)")
         Tdec = Tf if max_len is None else min(Tf, int(max_len))
         inter = self.dims.inter_channels
         ns = float(noise_scale)
@@ -226,9 +234,10 @@ class Engine:
         fl = torch.empty(B, dtype=torch.int64, device=self.device)
         ws = self._workspace("infer", self.lib.vsp_infer_workspace_bytes(self.ctx, B, Tp, Tf))
         with torch.cuda.device(self.device):
-            rc = self.lib.vsp_infer(self.ctx, self._stream(), B, Tp, Tf, -1 if max_len is None else int(max_len),
+            rc = self.lib.vsp_infer(self.ctx, self._stream(), B, Tp, Tf, -1 if max_len is None else Tdec,
                                     _ptr(ph), _ptr(ln), _ptr(sd), _ptr(ctl[0]), _ptr(ctl[1]), _ptr(ctl[2]),
-                                    float(duration_scale), float(pitch_scale), float(energy_scale), _ptr(nz), ns,
+                                    float(duration_scale), float(pitch_scale), float(energy_scale), _ptr(nz),
+                                    int(noise_seed) & (2**64 - 1), ns,
                                     _ptr(o), _ptr(x_mask), _ptr(z), _ptr(z_p), _ptr(m_p), _ptr(logs_p), _ptr(dur),
                                     _ptr(f0), _ptr(en), _ptr(fl), _ptr(ws), ws.numel())
         _lib.check(rc, self.ctx, "vsp_infer")
@@ -241,9 +250,35 @@ class Engine:
         ln = _dev_i64(lengths, self.device)
         B, C3, T = qkv.shape
         out = self._f(B, C3 // 3, T)
+        ws = self._workspace("attention", self.lib.vsp_attention_workspace_bytes(self.ctx, B, T))
         with torch.cuda.device(self.device):
-            rc = self.lib.vsp_attention(self.ctx, self._stream(), which, layer, B, T, _ptr(qkv), _ptr(ln), _ptr(out))
+            rc = self.lib.vsp_attention(self.ctx, self._stream(), which, layer, B, T, _ptr(qkv), _ptr(ln), _ptr(out),
+                                        _ptr(ws), ws.numel())
         _lib.check(rc, self.ctx, "vsp_attention")
+        return out
+
+    def wn_layer(self, which: int, layer: int, x, g, lengths, skip=None):
+        """``vsp_wn_layer``: one layer of modules.WN.forward (reference modules.py:148-176) of flow ``which``
+        (-1: the posterior encoder's WN).  Returns (x_new, skip_new); ``skip`` None starts the skip sum."""
+        x = _dev_f32(x, self.device).clone()
+        B, h, T = x.shape
+        g = _dev_f32(g, self.device).reshape(B, -1)
+        ln = _dev_i64(lengths, self.device)
+        acc = skip is not None
+        sk = _dev_f32(skip, self.device).clone() if acc else self._f(B, h, T)
+        ws = self._workspace("wn_layer", self.lib.vsp_wn_layer_workspace_bytes(self.ctx, which, B, T))
+        with torch.cuda.device(self.device):
+            rc = self.lib.vsp_wn_layer(self.ctx, self._stream(), which, layer, B, T, _ptr(x), _ptr(g), _ptr(ln), _ptr(sk),
+                                       int(acc), _ptr(ws), ws.numel())
+        _lib.check(rc, self.ctx, "vsp_wn_layer")
+        return x, sk
+
+    def randn(self, seed: int, *shape) -> torch.Tensor:
+        """``vsp_randn``: the library's own standard-normal stream (Philox4x32-10 keyed by ``seed``)."""
+        out = self._f(*shape)
+        with torch.cuda.device(self.device):
+            rc = self.lib.vsp_randn(self._stream(), int(seed) & (2**64 - 1), out.numel(), _ptr(out))
+        _lib.check(rc, self.ctx, "vsp_randn")
         return out
 
     def encoder(self, which: int, x, lengths) -> torch.Tensor:

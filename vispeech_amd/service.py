@@ -29,6 +29,48 @@ class Busy(RuntimeError):
     """Another synthesis is in flight (the reference answers such a request with a 'server busy' text)."""
 
 
+class _LockedStream:
+    """Iterator over the chunks of one streamed synthesis that OWNS the service's single-flight lock."""
+
+    def __init__(self, service: "SynthesisService", chunks: Iterator[bytes]):
+        self._service = service
+        self._chunks = chunks
+        self._held = True
+
+    def __iter__(self):
+        return self
+
+    def __next__(self) -> bytes:
+        if not self._held:
+            raise StopIteration
+        try:
+            return next(self._chunks)
+        except BaseException:          # exhausted (StopIteration) or failed: either way the synthesis is over
+            self.close()
+            raise
+
+    def close(self) -> None:
+        if self._held:
+            self._held = False
+            try:
+                self._chunks.close()
+            finally:
+                self._service.release()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pragma: no cover
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+
 class SynthesisService:
     """One model, one synthesis at a time, never queueing (reference inference_api.py:13, 37)."""
 
@@ -80,29 +122,28 @@ class SynthesisService:
     # ------------------------------------------------------------------ streamed
     def stream(self, batch, utterance: int = 0, noise=None) -> Iterator[bytes]:
         """PCM16 bytes of ``utterance``, one vocoder chunk (``chunk_frames`` frames) at a time.  Raises ``Busy``
-        at once when another synthesis is in flight; the lock is held until the generator is exhausted or
-        closed.  The concatenation equals ``synthesize`` byte for byte."""
+        at once when another synthesis is in flight.  The lock is owned by the returned ``_LockedStream`` and is
+        released exactly once: when the stream is exhausted, fails, is ``close()``d, or is dropped -- also when it
+        was never started (a plain generator that is never advanced would never run its ``finally``).  The
+        concatenation equals ``synthesize`` byte for byte."""
         if not self.try_acquire():
             raise Busy("another synthesis is in flight")
-        return self._stream_locked(batch, utterance, noise)
+        return _LockedStream(self, self._stream_chunks(batch, utterance, noise))
 
-    def _stream_locked(self, batch, utterance, noise) -> Iterator[bytes]:
-        try:
-            import torch
-            net, eng = self.net, self.net._engine
-            enc, frames, tf = self._encode(batch)
-            z_noise = noise if noise is not None else torch.randn(
-                enc["x_var"].shape[0], net.dims.inter_channels, tf, dtype=torch.float32, device=eng.device)
-            dec = eng.decode(enc, tf, z_noise, self.noise_scale, max_len=0)     # everything but the vocoder
-            hop, left = net.dims.total_upsample, int(frames[utterance]) * net.dims.total_upsample
-            for o in eng.generator_stream(dec["z"], enc["g"], self.chunk_frames):
-                if left <= 0:
-                    break
-                piece = pcm16(o[utterance, 0, : min(left, o.shape[2])])
-                left -= piece.size
-                yield piece.tobytes()
-        finally:
-            self.release()
+    def _stream_chunks(self, batch, utterance, noise) -> Iterator[bytes]:
+        import torch
+        net, eng = self.net, self.net._engine
+        enc, frames, tf = self._encode(batch)
+        z_noise = noise if noise is not None else torch.randn(
+            enc["x_var"].shape[0], net.dims.inter_channels, tf, dtype=torch.float32, device=eng.device)
+        dec = eng.decode(enc, tf, z_noise, self.noise_scale, max_len=0)     # everything but the vocoder
+        left = int(frames[utterance]) * net.dims.total_upsample
+        for o in eng.generator_stream(dec["z"], enc["g"], self.chunk_frames):
+            if left <= 0:
+                break
+            piece = pcm16(o[utterance, 0, : min(left, o.shape[2])])
+            left -= piece.size
+            yield piece.tobytes()
 
     # ------------------------------------------------------------------ helpers
     def _controls(self, batch):

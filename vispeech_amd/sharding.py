@@ -26,13 +26,19 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def _active() -> bool:
+    """A process group exists: the collectives run through it even with ONE rank (``bench.py --dist``: the RCCL
+    calls of the path execute on a single-GPU box)."""
+    return dist.is_available() and dist.is_initialized()
+
+
 def _world(group=None) -> int:
-    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    return dist.get_world_size(group) if _active() else 1
 
 
 def global_max(value: int, device, group=None) -> int:
     """MAX over ranks of one integer (the padded frame count of the global batch)."""
-    if _world(group) == 1:
+    if not _active():
         return int(value)
     t = torch.tensor([int(value)], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
@@ -42,7 +48,7 @@ def global_max(value: int, device, group=None) -> int:
 def broadcast_weights(engine, state_dict=None, src: int = 0, group=None) -> torch.Tensor:
     """Rank ``src`` folds + packs the checkpoint; the packed arena (one flat float tensor whose
     layout depends on the config only) is broadcast and adopted by every other rank."""
-    rank = dist.get_rank(group) if _world(group) > 1 else 0
+    rank = dist.get_rank(group) if _active() else 0
     if rank == src:
         if state_dict is None:
             raise ValueError("the source rank needs the state_dict")
@@ -50,7 +56,7 @@ def broadcast_weights(engine, state_dict=None, src: int = 0, group=None) -> torc
         arena = engine.finalize()
     else:
         arena = engine.adopt()
-    if _world(group) > 1:
+    if _active():
         dist.broadcast(arena, src=src, group=group)
     if rank != src:
         # the received bytes say what rank 0 packed (posterior encoder or not, configuration hash): check them
@@ -60,26 +66,105 @@ def broadcast_weights(engine, state_dict=None, src: int = 0, group=None) -> torc
     return arena
 
 
-def gather_batch(o: torch.Tensor, dst: int = 0, group=None) -> Optional[List[torch.Tensor]]:
-    """Gather per-rank waveform shards ``[b_r, 1, S]`` (same S on every rank: global padding; b_r may
-    differ by one) on ``dst``.  Returns the list of shards on ``dst`` and None elsewhere."""
+def shard_counts(n: int, world: int) -> List[int]:
+    """Utterances per rank of ``shard_range``: known on every rank without communication."""
+    return [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
+
+
+class BatchGatherer:
+    """The per-batch waveform gather on ``dst`` (exchange 3 above) as a PERSISTENT object.
+
+    Shard sizes come from ``shard_range`` (no size exchange, no host read in the step), the receive buffers on
+    ``dst`` are allocated once, and the collective runs on a side stream behind an event recorded on the compute
+    stream: ``start(o)`` returns at once, so the next step's kernels overlap the transfer over xGMI; ``wait()``
+    makes the current stream wait for it and hands out the shards.  One gather is in flight at a time (``start``
+    first waits for the previous one).  On CPU tensors (gloo, the tests) the same calls run without streams."""
+
+    def __init__(self, counts: Sequence[int], sample_shape: Sequence[int], dtype=torch.float32, device="cpu",
+                 dst: int = 0, group=None):
+        self.world = _world(group)
+        if len(counts) != self.world:
+            raise ValueError("one shard size per rank")
+        self.collective = _active()
+        self.rank = dist.get_rank(group) if self.collective else 0
+        self.counts = [int(c) for c in counts]
+        self.dst, self.group = dst, group
+        self.device = torch.device(device)
+        self.shape = tuple(int(x) for x in sample_shape)
+        bmax = max(self.counts)
+        mk = lambda: torch.empty((bmax,) + self.shape, dtype=dtype, device=self.device)
+        self.recv = [mk() for _ in range(self.world)] if (self.rank == dst and self.collective) else None
+        # equal-size operands for the collective: a short shard is staged in a persistent, zero-tailed buffer
+        self.stage = torch.zeros((bmax,) + self.shape, dtype=dtype, device=self.device) \
+            if self.collective and self.counts[self.rank] < bmax else None
+        self.side = torch.cuda.Stream(self.device) if self.device.type == "cuda" and self.collective else None
+        self._work = None
+        self._done = None
+        self._local = None
+
+    def start(self, o: torch.Tensor) -> None:
+        if tuple(o.shape) != (self.counts[self.rank],) + self.shape:
+            raise ValueError(f"shard has shape {tuple(o.shape)}, expected {(self.counts[self.rank],) + self.shape}")
+        self.wait()
+        if not self.collective:
+            self._local = o
+            return
+        if self.side is None:
+            send = o.contiguous()
+            if self.stage is not None:
+                self.stage[: o.shape[0]].copy_(send)
+                send = self.stage
+            self._work = dist.gather(send, self.recv, dst=self.dst, group=self.group, async_op=True)
+            return
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ready)
+            send = o.contiguous()
+            if self.stage is not None:
+                self.stage[: o.shape[0]].copy_(send, non_blocking=True)
+                send = self.stage
+            o.record_stream(self.side)
+            self._work = dist.gather(send, self.recv, dst=self.dst, group=self.group, async_op=True)
+            self._work.wait()              # orders the side stream (not the host) behind the collective
+            self._done = torch.cuda.Event()
+            self._done.record(self.side)
+
+    def wait(self) -> Optional[List[torch.Tensor]]:
+        """Shards in rank order on ``dst`` (views of the persistent buffers: valid until the next ``start``), None
+        elsewhere.  Stream-ordered on the GPU: the host does not block."""
+        if not self.collective:
+            o, self._local = self._local, None
+            return None if o is None else [o]
+        if self._work is None:
+            return None
+        if self.side is None:
+            self._work.wait()
+        else:
+            torch.cuda.current_stream(self.device).wait_event(self._done)
+        self._work = None
+        if self.rank != self.dst:
+            return None
+        return [b[:c] for b, c in zip(self.recv, self.counts)]
+
+
+def gather_batch(o: torch.Tensor, dst: int = 0, group=None, counts: Optional[Sequence[int]] = None) -> Optional[List[torch.Tensor]]:
+    """One-shot form: gather per-rank waveform shards ``[b_r, 1, S]`` (same S on every rank: global padding; b_r may
+    differ by one) on ``dst``.  ``counts`` = shard sizes per rank (``shard_counts``); without them they are
+    exchanged first (one small all_gather and a host read -- keep that out of timed loops: ``BatchGatherer``).
+    Returns the list of shards on ``dst`` and None elsewhere."""
     world = _world(group)
-    if world == 1:
+    if not _active():
         return [o]
-    rank = dist.get_rank(group)
-    nb = torch.tensor([o.shape[0]], dtype=torch.int64, device=o.device)
-    counts = [torch.zeros_like(nb) for _ in range(world)]
-    dist.all_gather(counts, nb, group=group)
-    bmax = int(max(int(c.item()) for c in counts))
-    if o.shape[0] < bmax:                      # equal-size buffers for the collective
-        pad = torch.zeros((bmax - o.shape[0],) + tuple(o.shape[1:]), dtype=o.dtype, device=o.device)
-        o = torch.cat([o, pad], dim=0)
-    o = o.contiguous()
-    bufs = [torch.empty_like(o) for _ in range(world)] if rank == dst else None
-    dist.gather(o, bufs, dst=dst, group=group)
-    if rank != dst:
-        return None
-    return [b[: int(c.item())] for b, c in zip(bufs, counts)]
+    if counts is None:
+        nb = torch.tensor([o.shape[0]], dtype=torch.int64, device=o.device)
+        got = [torch.zeros_like(nb) for _ in range(world)]
+        dist.all_gather(got, nb, group=group)
+        counts = torch.cat(got).tolist()
+    g = BatchGatherer(counts, o.shape[1:], o.dtype, o.device, dst, group)
+    g.start(o)
+    shards = g.wait()
+    return None if shards is None else [s.clone() for s in shards]
 
 
 def infer_sharded(net, phonemes, lengths, sid, *, noise: Optional[torch.Tensor] = None, dst: int = 0, group=None,
@@ -92,7 +177,7 @@ def infer_sharded(net, phonemes, lengths, sid, *, noise: Optional[torch.Tensor] 
     count without communication; otherwise it is the all-reduce MAX of the local maxima that
     ``net.infer`` reports.  Returns (o_full [B,1,S] on ``dst`` else None, local result tuple)."""
     world = _world(group)
-    rank = dist.get_rank(group) if world > 1 else 0
+    rank = dist.get_rank(group) if _active() else 0
     B = phonemes.shape[0]
     lo, hi = shard_range(B, rank, world)
     sl = slice(lo, hi)
@@ -107,6 +192,6 @@ def infer_sharded(net, phonemes, lengths, sid, *, noise: Optional[torch.Tensor] 
         raise ValueError("pass frame_counts or noise so that all ranks pad to the same frame count")
     t_f = global_max(t_f, phonemes.device, group)
     out = net.infer(phonemes[sl], lengths[sl], sid=sid[sl], noise=None if noise is None else noise[sl], t_f=t_f, **kw)
-    shards = gather_batch(out[0], dst=dst, group=group)
+    shards = gather_batch(out[0], dst=dst, group=group, counts=shard_counts(B, world))
     full = torch.cat(shards, dim=0) if shards is not None else None
     return full, out
