@@ -147,12 +147,12 @@ __global__ void __launch_bounds__(64 * WM * WN, F16S ? 2 : 1) conv1d_f32_mfma(Co
       }
   unsigned* const ph = reinterpret_cast<unsigned*>(xs);          // F16S: hi image [16][LWP] words
   unsigned* const pl = ph + (CONV_CK / 2) * LWP;                 //       lo image
+  // hi = the fp32 value truncated to f16 precision (one v_and_b32; packed without rounding by v_cvt_pkrtz, which also
+  // saturates instead of producing inf), lo = the exact fp32 residual * 2^11 (gen16.hip: g16_split2)
   auto split_pair = [&](float x0, float x1, unsigned& whi, unsigned& wlo) {
-    const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
-    const f16x2 hi = {h0, h1};
-    const f16x2 lo = {(_Float16)((x0 - (float)h0) * 2048.f), (_Float16)((x1 - (float)h1) * 2048.f)};
-    whi = __builtin_bit_cast(unsigned, hi);
-    wlo = __builtin_bit_cast(unsigned, lo);
+    const float h0 = __uint_as_float(__float_as_uint(x0) & 0xffffe000u), h1 = __uint_as_float(__float_as_uint(x1) & 0xffffe000u);
+    whi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h0, h1));
+    wlo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz((x0 - h0) * 2048.f, (x1 - h1) * 2048.f));
   };
 
   const float4* wp4 = reinterpret_cast<const float4*>(a.wp);
@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(64 * WM * WN, F16S ? 2 : 1) conv1d_f32_mfma(Co
     }
   };
   // conversion of a staged pair of channels x four times: leaky-relu as max(x, slope x) (0 <= slope <= 1; slope 1 =
-  // none), packed f32 arithmetic, the rounded hi pinned before the residual is taken (gen16.hip: g16_split4)
+  // none), packed f32 arithmetic, the truncating split of split_pair
   typedef float f32x2v __attribute__((ext_vector_type(2)));
   [[maybe_unused]] const float slope_eff = a.in_act ? a.in_slope : 1.f;
   [[maybe_unused]] auto st_write = [&](int chunk) {
@@ -263,12 +263,10 @@ __global__ void __launch_bounds__(64 * WM * WN, F16S ? 2 : 1) conv1d_f32_mfma(Co
         const f32x2v y = x * slope_eff;
         asm("v_max_f32 %0, %1, %2" : "=v"(x.x) : "v"(x.x), "v"(y.x));
         asm("v_max_f32 %0, %1, %2" : "=v"(x.y) : "v"(x.y), "v"(y.y));
-        f16x2 hi = __builtin_convertvector(x, f16x2);
-        asm volatile("" : "+v"(hi));
-        const f32x2v back = __builtin_convertvector(hi, f32x2v);
-        const f16x2 lo = __builtin_convertvector((x - back) * 2048.f, f16x2);
-        wh4[u] = __builtin_bit_cast(unsigned, hi);
-        wl4[u] = __builtin_bit_cast(unsigned, lo);
+        const f32x2v hf = {__uint_as_float(__float_as_uint(x.x) & 0xffffe000u), __uint_as_float(__float_as_uint(x.y) & 0xffffe000u)};
+        const f32x2v lf = (x - hf) * 2048.f;          // (packed arithmetic: v_pk_add_f32, v_pk_mul_f32)
+        wh4[u] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(hf.x, hf.y));
+        wl4[u] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lf.x, lf.y));
       }
       const int o = (wave + j * NW) * LWP + 4 * lane;
       *reinterpret_cast<u32x4*>(ph + o) = u32x4{wh4[0], wh4[1], wh4[2], wh4[3]};
