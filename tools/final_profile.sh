@@ -13,8 +13,8 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" -o p -- python3
 python3 "$R/tools/traffic_from_pmc.py" 'g16_conv|g16_pair|g16_chain' "$O/pmc_fetch/p_counter_collection.csv" "$O/pmc_write/p_counter_collection.csv" f16s 64 489 > "$O/traffic.json" || true
 cp "$O/traffic.json" "$R/profiles/traffic.json"   # the bench lines below report THIS build's measured traffic
 python3 "$R/bench.py" --steps 20 --warmup 5 > "$O/bench.json" 2>> "$O/bench.err"
-python3 "$R/bench.py" --workload C2 --steps 10 --no-cpu-baseline > "$O/bench_c2.json" 2>> "$O/bench.err"
-python3 "$R/bench.py" --workload C5 --steps 10 --no-cpu-baseline > "$O/bench_c5.json" 2>> "$O/bench.err"
+python3 "$R/bench.py" --workload C2 --steps 10 --cpu-runs 1 > "$O/bench_c2.json" 2>> "$O/bench.err"
+python3 "$R/bench.py" --workload C5 --steps 10 > "$O/bench_c5.json" 2>> "$O/bench.err"
 python3 "$R/bench.py" --controls duration --steps 10 --cpu-sample 4 > "$O/bench_controls_duration.json" 2>> "$O/bench.err"
 python3 "$R/bench.py" --controls none --steps 5 --cpu-sample 2 > "$O/bench_controls_none.json" 2>> "$O/bench.err"
 VSP_GENERATOR=f16 python3 "$R/bench.py" --cpu-sample 2 > "$O/bench_f16mode.json" 2>> "$O/bench.err"
