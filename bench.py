@@ -226,10 +226,13 @@ def main():
     use_dist = world > 1 or args.dist          # --dist: the collectives run (through RCCL) even with one rank
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # a collective that does not complete raises after this timeout instead of hanging the run
+        import datetime
+        pg_timeout = datetime.timedelta(seconds=int(os.environ.get("VSP_BENCH_PG_TIMEOUT", "300")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=pg_timeout)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=pg_timeout)
     n_ranks_seen = dist.get_world_size() if use_dist else 1
 
     dims = ModelDims()

@@ -261,14 +261,15 @@ void run_encoder_masked(Run& r, const EncoderW& E, int B, int T, T3 x_in, const 
 
 // modules.WN.forward (reference modules.py:148-176; dilation_rate 1) on H [B][h][T]: H is the running
 // residual stream (destroyed), OUT receives the masked skip sum.  gc: nl * 2h conditioning rows.
-void run_wn(Run& r, const Conv& cond, const std::vector<Conv>& in, const std::vector<Conv>& res,
-            const std::vector<Conv>& skip, int nl, int B, int T, T3 H, T3 ACT, T3 OUT, float* gc, const float* g,
+// cond != null: cond_layer(g) is evaluated here into gc [B][nl * 2h]; null: gc already holds it, batch stride gc_bs.
+void run_wn(Run& r, const Conv* cond, const std::vector<Conv>& in, const std::vector<Conv>& res,
+            const std::vector<Conv>& skip, int nl, int B, int T, T3 H, T3 ACT, T3 OUT, float* gc, long gc_bs, const float* g,
             const int64_t* lengths) {
   const int h = r.ctx->cfg.hidden_channels;
-  r.cond(cond, g, gc, B);
+  if (cond) r.cond(*cond, g, gc, B);
   for (int l = 0; l < nl; ++l) {
     ConvArgs a = r.args(in[l], H, ACT, T, T);
-    a.act = 2; a.cond = gc ? gc + (size_t)l * 2 * h : nullptr; a.cond_bs = 2L * h * nl;
+    a.act = 2; a.cond = gc ? gc + (size_t)l * 2 * h : nullptr; a.cond_bs = gc_bs;
     r.conv(a, B);
     if (l < nl - 1) {
       // res_skip_layers[l] (modules.py:165-172) as one launch with two destinations: rows [0, h) are the in-place
@@ -296,7 +297,10 @@ void run_flow(Run& r, int B, int T, T3 z, const float* g, const int64_t* lengths
   const Model& m = r.ctx->model;
   const int h = c.hidden_channels, half = c.inter_channels / 2, fl = c.flow_layers;
   T3 H = r.ws.t3(B, h, T), ACT = r.ws.t3(B, h, T), OUT = r.ws.t3(B, h, T);
-  float* gc = r.ws.f((size_t)B * 2 * h * fl);
+  // cond_layer(g) of all coupling layers: one launch (reference modules.py:153-155, once per WN.forward)
+  const long gcs = (long)c.n_flows * 2 * h * fl;
+  float* gc = r.ws.f((size_t)B * gcs);
+  r.cond(m.flow_cond_all, g, gc, B);
   for (int n = 0; n < c.n_flows; ++n) {
     const int i = reverse ? c.n_flows - 1 - n : n;
     const FlowW& F = m.flows[i];
@@ -305,7 +309,7 @@ void run_flow(Run& r, int B, int T, T3 z, const float* g, const int64_t* lengths
     ConvArgs a = r.args(F.pre, x0, H, T, T);
     a.lengths = lengths; a.mask_post = 1;
     r.conv(a, B);
-    run_wn(r, F.cond, F.in, F.res, F.skip, fl, B, T, H, ACT, OUT, gc, g, lengths);
+    run_wn(r, nullptr, F.in, F.res, F.skip, fl, B, T, H, ACT, OUT, gc ? gc + (size_t)i * 2 * h * fl : nullptr, gcs, g, lengths);
     // m = post(out) * mask ; x1 = (x1 -/+ m) * mask
     a = r.args(F.post, OUT, x1, T, T);
     a.lengths = lengths; a.mask_pre = 1; a.alpha = reverse ? -1.f : 1.f;
@@ -327,12 +331,11 @@ void run_posterior(Run& r, int B, int T, T3 y, const int64_t* lengths, const flo
   ConvArgs a = r.args(Q.pre, y, H, T, T);
   a.lengths = lengths; a.mask_post = 1;
   r.conv(a, B);
-  run_wn(r, Q.cond, Q.in, Q.res, Q.skip, ql, B, T, H, ACT, OUT, gc, g, lengths);
-  a = r.args(Q.proj_m, OUT, M, T, T);
+  run_wn(r, &Q.cond, Q.in, Q.res, Q.skip, ql, B, T, H, ACT, OUT, gc, 2L * h * ql, g, lengths);
+  // proj: m and logs rows in one launch, two destinations (reference models.py:238-239: stats = proj(x) * mask, split)
+  a = r.args(Q.proj, OUT, M, T, T);
   a.lengths = lengths; a.mask_post = 1;
-  r.conv(a, B);
-  a = r.args(Q.proj_s, OUT, LOGS, T, T);
-  a.lengths = lengths; a.mask_post = 1;
+  a.split_row = c.inter_channels; a.out2 = LOGS.p; a.o2_bs = LOGS.bs; a.o2_cs = LOGS.cs; a.mask_post2 = 1;
   r.conv(a, B);
   if (r.ok()) {
     // z = (m + eps * exp(logs)) * mask   (contiguous [B][inter][T] outputs)
@@ -941,11 +944,10 @@ static int decode_impl(vsp_ctx* ctx, hipStream_t s, Ws& ws, int B, int Tp, int T
   }
   run_encoder_masked(r, m.enc[2], B, Tf, XF, frame_lengths, HF);
   const T3 MP = ext(m_p, inter, Tf), LP = ext(logs_p, inter, Tf), Z = ext(z, inter, Tf);
-  ConvArgs a = r.args(m.proj_m, HF, MP, Tf, Tf);
+  // Projection (reference models.py:526-529): one 1x1 convolution, m_p and logs_p rows to their own tensors
+  ConvArgs a = r.args(m.proj, HF, MP, Tf, Tf);
   a.lengths = frame_lengths; a.mask_post = 1;
-  r.conv(a, B);
-  a = r.args(m.proj_s, HF, LP, Tf, Tf);
-  a.lengths = frame_lengths; a.mask_post = 1;
+  a.split_row = inter; a.out2 = LP.p; a.o2_bs = LP.bs; a.o2_cs = LP.cs; a.mask_post2 = 1;
   r.conv(a, B);
   if (live) {
     const long n = (long)B * inter * Tf;

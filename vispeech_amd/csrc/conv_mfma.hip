@@ -549,7 +549,7 @@ __global__ void __launch_bounds__(64 * WM * WN, F16S ? 2 : 1) conv1d_f32_mfma(Co
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const int q = t0 + (wn * NT + nt) * 32 + l31;
-          const bool qin = q < a.Nq;
+          const bool qin = q < a.Nq, keep = !a.mask_post2 || q < len;
           int oo[16];
           unsigned pv[16];
 #pragma unroll
@@ -563,6 +563,7 @@ __global__ void __launch_bounds__(64 * WM * WN, F16S ? 2 : 1) conv1d_f32_mfma(Co
             float v = acc[mt][nt][r];
             if (a.bias) v += bv[r >> 2][r & 3];
             if (a.acc_prev2) v += __uint_as_float(pv[r]);
+            if (!keep) v = 0.f;
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro2, oo[r], 0, 0);
           }
         }

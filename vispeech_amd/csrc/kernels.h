@@ -40,6 +40,7 @@ struct ConvArgs {
   // 32; 0 = off) go to out2[row - split_row] (+ out2 when acc_prev2) with no residual, mask or scaling; the rows
   // below it keep the epilogue above
   int split_row; float* out2; long o2_bs, o2_cs; int acc_prev2;
+  int mask_post2;             // ... except this mask on the second destination (the two halves of one projection)
 };
 
 // the tile shape is chosen from M and Nq

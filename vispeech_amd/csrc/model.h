@@ -50,7 +50,7 @@ struct FlowW {
 };
 // PosteriorEncoder (reference models.py:212-241): pre 1x1, WN (k5, dilation 1, n layers), proj 1x1.
 struct PosteriorW {
-  Conv pre, cond, proj_m, proj_s;
+  Conv pre, cond, proj;  // proj: m rows, then logs rows (one launch, two destinations)
   std::vector<Conv> in, res, skip;
 };
 struct ResBlockW {
@@ -70,7 +70,8 @@ struct Model {
   Conv en_cond, en_c1, en_c2;
   size_t en_g1 = 0, en_b1 = 0, en_g2 = 0, en_b2 = 0, en_lw = 0, en_lb = 0;
   size_t ppre_w = 0, ppre_b = 0, epre_w = 0, epre_b = 0;
-  Conv proj_m, proj_s;
+  Conv proj;            // project.proj: rows [0, inter) = m_p, [inter, 2 inter) = logs_p -- ONE launch with two destinations
+  Conv flow_cond_all;   // the cond_layer of every coupling layer's WN as one 1x1 convolution on g (FlowW::cond = its rows)
   std::vector<FlowW> flows;  // index = flow layer i (applied in order n_flows-1 .. 0)
   Conv stft;            // windowed one-sided DFT basis (rows: cos 0..spec-1, then -sin), planned when cfg.spec_channels > 0
   PosteriorW enc_q;     // planned when cfg.spec_channels > 0

@@ -217,6 +217,7 @@ int plan_model(vsp_ctx* ctx) {
     return ctx->fail(VSP_ERR_UNSUPPORTED, "n_speakers > 1 and gin_channels > 0 are required (the reference's "
                                           "EnergyPredictor dereferences g unconditionally, frame_prior_network.py:120)");
   if (inter % 2) return ctx->fail(VSP_ERR_ARG, "inter_channels must be even");
+  if (inter % 32) return ctx->fail(VSP_ERR_UNSUPPORTED, "inter_channels must be a multiple of 32 (the projection's two halves are row tiles of one launch)");
   if (2 * c.window_size + 1 > 16) return ctx->fail(VSP_ERR_UNSUPPORTED, "window_size > 7");
   if (c.n_upsamples < 1 || c.n_upsamples > VSP_MAX_LIST || c.n_resblock_kernels < 1 ||
       c.n_resblock_kernels > VSP_MAX_LIST || c.n_resblock_dilations < 1 || c.n_resblock_dilations > VSP_MAX_LIST)
@@ -245,17 +246,22 @@ int plan_model(vsp_ctx* ctx) {
   m.en_lw = p.raw(e); m.en_lb = p.raw(1);
   m.ppre_w = p.raw((size_t)h * 3); m.ppre_b = p.raw(h);
   m.epre_w = p.raw((size_t)h * 3); m.epre_b = p.raw(h);
-  m.proj_m = p.conv(inter, h, 1, 1, 0, true);
-  m.proj_s = p.conv(inter, h, 1, 1, 0, true);
+  m.proj = p.conv(2 * inter, h, 1, 1, 0, true);
   // flows: applied in order n_flows-1 .. 0, each preceded by a Flip (reference models.py:202-209);
   // the flip is folded into channel order: before layer i the tensor has seen n_flows - i flips.
   m.flows.resize(c.n_flows);
   const int half = inter / 2, fk = c.flow_kernel, fl = c.flow_layers;
+  // every coupling layer's cond_layer(g) in ONE launch: the packed image is m-tile major, so the rows of flow i are a
+  // contiguous run of it (and of the bias vector) -- FlowW::cond is a view
+  m.flow_cond_all = p.conv(c.n_flows * 2 * h * fl, gin, 1, 1, 0, true);
   for (int i = 0; i < c.n_flows; ++i) {
     FlowW& F = m.flows[i];
     F.flipped = ((c.n_flows - i) % 2) == 1;
     F.pre = p.conv(h, half, 1, 1, 0, true);
-    F.cond = p.conv(2 * h * fl, gin, 1, 1, 0, true);
+    F.cond = m.flow_cond_all;
+    F.cond.M = 2 * h * fl;
+    F.cond.w = m.flow_cond_all.w + (size_t)i * packed_conv_floats(2 * h * fl, gin, 1);
+    F.cond.b = m.flow_cond_all.b + (long)i * 2 * h * fl;
     for (int l = 0; l < fl; ++l) {
       F.in.push_back(p.conv(2 * h, h, fk, 1, (fk - 1) / 2, true));
       if (l < fl - 1) F.res.push_back(p.conv(2 * h, h, 1, 1, 0, true));   // residual rows, then skip rows: one launch
@@ -279,8 +285,7 @@ int plan_model(vsp_ctx* ctx) {
       if (l < ql - 1) Q.res.push_back(p.conv(2 * h, h, 1, 1, 0, true));
       Q.skip.push_back(p.conv(h, h, 1, 1, 0, true));
     }
-    Q.proj_m = p.conv(inter, h, 1, 1, 0, true);
-    Q.proj_s = p.conv(inter, h, 1, 1, 0, true);
+    Q.proj = p.conv(2 * inter, h, 1, 1, 0, true);
   }
   // generator (its channel-major f32 form is the second implementation kept for VSP_GENERATOR=f32).
   // ctx->gen_mode holds the requested mode here (vsp_create parses VSP_GENERATOR before planning); it falls back to 0
@@ -530,8 +535,7 @@ int fill_model(vsp_ctx* ctx, std::vector<float>& arena) {
   f.copy_raw(m.ppre_b, "pitch_prenet.bias", h);
   f.copy_raw(m.epre_w, "energy_prenet.weight", (size_t)h * 3);
   f.copy_raw(m.epre_b, "energy_prenet.bias", h);
-  f.conv_plain(m.proj_m, "project.proj.weight", "project.proj.bias", 0);
-  f.conv_plain(m.proj_s, "project.proj.weight", "project.proj.bias", inter);
+  f.conv_plain(m.proj, "project.proj.weight", "project.proj.bias", 0);
 
   const int half = inter / 2, fl = c.flow_layers, fk = c.flow_kernel;
   for (int i = 0; i < c.n_flows && f.ok; ++i) {
@@ -592,8 +596,7 @@ int fill_model(vsp_ctx* ctx, std::vector<float>& arena) {
       const PosteriorW& Q = m.enc_q;
       f.conv_plain(Q.pre, "enc_q.pre.weight", "enc_q.pre.bias");
       fill_wn(f, "enc_q.enc", Q.cond, Q.in, Q.res, Q.skip, c.posterior_layers, h, gin, fk);
-      f.conv_plain(Q.proj_m, "enc_q.proj.weight", "enc_q.proj.bias", 0);
-      f.conv_plain(Q.proj_s, "enc_q.proj.weight", "enc_q.proj.bias", inter);
+      f.conv_plain(Q.proj, "enc_q.proj.weight", "enc_q.proj.bias", 0);
       m.has_vc = f.ok;
     }
   }
