@@ -552,13 +552,14 @@ __device__ __forceinline__ void g16_pair_wait(int pieces, int groups) {
 // The arithmetic per output (chunk-major, tap-minor, HH / CROSS / CROSS per step, bias in the accumulator) is that of
 // g16_conv, so the result is bit-identical to the two-launch path.
 //   NCH = C / 32 (1 or 2); G = taps per ring slot.
-template <int NCH, int G, int TERMS, int NWV>
+template <int NCH, int G, int TERMS, int NWV, int NS = 3>
 __global__ void __launch_bounds__(64 * NWV, 4) g16_pair(ClPairArgs a) {
   constexpr int MW = 2 * NCH, NW = 2, C = 32 * NCH;
   constexpr int BT = 32 * NWV, WR = BT + G16_HALO, PL = WR * 16, XIMG = 4 * PL, XBUF = 2 * XIMG;
   constexpr int TAPB = MW * 2048;               // bytes of one tap in a ring slot
   constexpr int SLOT = G * TAPB;
-  constexpr int NS = 3, RPS = 8 * NWV, NL = (WR + RPS - 1) / RPS;
+  constexpr int RPS = 8 * NWV, NL = (WR + RPS - 1) / RPS;
+  static_assert(NS == 2 || NS == 3, "ring depth: NS - 1 slices are requested ahead of the one being multiplied");
   constexpr int NPT = 2 * MW;                   // 1 KiB pieces per tap
   constexpr int NBWMAX = (G * NPT + NWV - 1) / NWV;
   constexpr bool EARLY_RES = NCH == 1 && TERMS == 3;
@@ -576,6 +577,17 @@ __global__ void __launch_bounds__(64 * NWV, 4) g16_pair(ClPairArgs a) {
   const int id = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (orig >> 3);
   const int b = id / a.tiles, tile = id - b * a.tiles;
 
+#ifdef G16_STAMPS
+  // (diagnostic build, tools/stamps_pair.py: wave 0 of every 197th block of the VSP_STAMP_PAIR-th launch of this shape)
+  int stamp_slot = -1, stamp_n = 0;
+  if (wave == 0 && orig % 197 == 5 && (a.terms & 0x100)) {
+    unsigned sl_ = 0;
+    if (lane == 0) sl_ = atomicAdd(&g_g16_stamp_count, 1u);
+    sl_ = __builtin_amdgcn_readfirstlane(sl_);
+    stamp_slot = sl_ < (unsigned)G16_NSAMPLE ? (int)sl_ : -1;
+  }
+  G16_STAMPT(1);
+#endif
   const int K = a.K, p2 = (K - 1) >> 1, p1 = a.dil * p2;
   const int R2 = BT - (K - 1);                  // output columns per block
   const int t0 = tile * R2;                     // first output column
@@ -692,8 +704,10 @@ __global__ void __launch_bounds__(64 * NWV, 4) g16_pair(ClPairArgs a) {
   init_acc(a.b1);
   x_issue(0);
   int pc_a = dma_next(0);            // pieces of slice s + 1 / s + 2 issued by this wave (for the counted waits)
-  int pc_b = dma_next(1);
+  int pc_b = NS == 3 ? dma_next(1) : 0;
+  G16_STAMPT(2);                     // requests out
   x_write();
+  G16_STAMPT(3);                     // x window converted and written
   int xl_a = 0, xl_b = 0;            // window loads issued behind slice s + 1 / s + 2
   int slot = 0;
   // at the top of step s: slices s and s + 1 are in flight or landed; pc_a / pc_b = my pieces of s + 1 / s + 2
@@ -705,10 +719,17 @@ __global__ void __launch_bounds__(64 * NWV, 4) g16_pair(ClPairArgs a) {
   int chunk = 0, sl = 0;
   for (int s = 0; s < S1; ++s) {
     // slice s has landed: issued after it are slice s + 1 and the window loads of the last two steps
-    g16_pair_wait<NL>(pc_nxt, xl_a + xl_b);
+    // (two slots: slice s went out a step ago, AFTER the window request of the step before that: only the last step's
+    // request is younger)
+    G16_STAMPT(10);
+    g16_pair_wait<NL>(pc_nxt, NS == 3 ? xl_a + xl_b : xl_b);
+    G16_STAMPT(11);
     G16_BARRIER();                                   // slice s (and a freshly written window) visible to all
+    G16_STAMPT(12);
     pc_cur = pc_nxt;
-    pc_nxt = s + 2 < S ? dma_next(slot == 0 ? 2 : slot - 1) : 0;     // slot of slice s - 1
+    if constexpr (NS == 3) pc_nxt = s + 2 < S ? dma_next(slot == 0 ? 2 : slot - 1) : 0;     // slot of slice s - 1
+    else { if (s + 1 < S) (void)dma_next(slot ^ 1); pc_nxt = 0; }   // two slots: slice s + 1 goes out now, nothing else is in flight at the next wait
+    G16_STAMPT(13);
     xl_a = xl_b;
     xl_b = 0;
     const bool last_sl = sl == ns - 1;
@@ -718,10 +739,13 @@ __global__ void __launch_bounds__(64 * NWV, 4) g16_pair(ClPairArgs a) {
     }
     const int tap0 = sl * G;
     slice(slot, tap0, (K - tap0) < G ? (K - tap0) : G, a.dil);
+    G16_STAMPT(14);
     if constexpr (NCH > 1) {
       if (last_sl && chunk + 1 < NCH) {
         G16_BARRIER();                               // every wave is done reading this chunk's window
+        G16_STAMPT(15);
         x_write();
+        G16_STAMPT(16);
       }
     }
     slot = slot == NS - 1 ? 0 : slot + 1;
@@ -743,13 +767,16 @@ __global__ void __launch_bounds__(64 * NWV, 4) g16_pair(ClPairArgs a) {
     }
   }
 
+  G16_STAMPT(20);
   // ================= conv2 =================
   init_acc(a.b2);
 #pragma unroll
   for (int c2 = 0; c2 < NCH; ++c2) {
     // t image chunk c2 = conv1 output channels [32 c2, 32 c2 + 32) = m-tiles 2 c2, 2 c2 + 1: a lane's four channels
     // 16 i + 4 q4 .. + 3 sit in plane 2 (i & 1) + (q4 >> 1) at byte 8 (q4 & 1) of the row's 16
+    G16_STAMPT(21);
     G16_BARRIER();                                   // nobody still reads the region (window / previous t chunk)
+    G16_STAMPT(22);
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
@@ -760,21 +787,29 @@ __global__ void __launch_bounds__(64 * NWV, 4) g16_pair(ClPairArgs a) {
         *reinterpret_cast<f16x4*>(dst) = eh;
         if constexpr (TERMS == 3) *reinterpret_cast<f16x4*>(dst + XIMG) = el;
       }
+    G16_STAMPT(23);                                  // image chunk written
     for (int sl2 = 0; sl2 < ns; ++sl2) {
       const int s = S1 + c2 * ns + sl2;
-      g16_pair_wait<NL>(pc_nxt, xl_a + xl_b);
+      G16_STAMPT(10);
+      g16_pair_wait<NL>(pc_nxt, NS == 3 ? xl_a + xl_b : xl_b);
+      G16_STAMPT(11);
       G16_BARRIER();
+      G16_STAMPT(12);
       pc_cur = pc_nxt;
-      pc_nxt = s + 2 < S ? dma_next(slot == 0 ? 2 : slot - 1) : 0;
+      if constexpr (NS == 3) pc_nxt = s + 2 < S ? dma_next(slot == 0 ? 2 : slot - 1) : 0;
+      else { if (s + 1 < S) (void)dma_next(slot ^ 1); pc_nxt = 0; }
+      G16_STAMPT(13);
       xl_a = xl_b;
       xl_b = 0;
       const int tap0 = sl2 * G;
       slice(slot, tap0, (K - tap0) < G ? (K - tap0) : G, 1);
+      G16_STAMPT(14);
       slot = slot == NS - 1 ? 0 : slot + 1;
     }
   }
 
   // ---- epilogue: y = conv2 + x (+ previous resblock sum) (/ div); columns >= R2 belong to the next tile
+  G16_STAMPT(30);
 #pragma unroll
   for (int i = 0; i < MW; ++i)
 #pragma unroll
@@ -790,15 +825,20 @@ __global__ void __launch_bounds__(64 * NWV, 4) g16_pair(ClPairArgs a) {
       if (a.div != 1.f) v /= a.div;
       __builtin_amdgcn_raw_buffer_store_b128(g16_as_u32x4(v), ro, off, 0, 0);
     }
+#ifdef G16_STAMPS
+  G16_STAMPT(31);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  G16_STAMPT(32);
+#endif
 }
 
-template <int NCH, int G, int TERMS, int NWV>
+template <int NCH, int G, int TERMS, int NWV, int NS = 3>
 static hipError_t launch_g16_pair_tile(ClPairArgs a, int B, hipStream_t s) {
   constexpr int BT = 32 * NWV;
-  constexpr size_t lds = (size_t)2 * 4 * (BT + G16_HALO) * 16 + (size_t)3 * G * 2 * NCH * 2048;
+  constexpr size_t lds = (size_t)2 * 4 * (BT + G16_HALO) * 16 + (size_t)NS * G * 2 * NCH * 2048;
   static_assert(lds <= (NWV == 8 ? 80 : 160) * 1024, "two 8-wave blocks or one 16-wave block per CU");
   static bool attr_set = false;
-  auto kern = g16_pair<NCH, G, TERMS, NWV>;
+  auto kern = g16_pair<NCH, G, TERMS, NWV, NS>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -808,6 +848,14 @@ static hipError_t launch_g16_pair_tile(ClPairArgs a, int B, hipStream_t s) {
   a.tiles = (a.T + R2 - 1) / R2;
   const long n = (long)a.tiles * B;
   if (n <= 0 || n > 0x7fffffffL) return hipErrorInvalidValue;
+#ifdef G16_STAMPS
+  {  // stamps only in the VSP_STAMP_PAIR-th launch of this kernel shape (0-based)
+    static int launch_no = 0;
+    static int target = -2;
+    if (target == -2) { const char* e = getenv("VSP_STAMP_PAIR"); target = e ? atoi(e) : -1; }
+    if (launch_no++ == target) a.terms |= 0x100;
+  }
+#endif
   hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(64 * NWV), lds, s, a);
   return hipGetLastError();
 }
@@ -830,7 +878,11 @@ hipError_t launch_g16_pair(const ClPairArgs& a, int B, hipStream_t s) {
 #endif
   if (a.terms == 1)
     return a.C == 32 ? launch_g16_pair_tile<1, 2, 1, 8>(a, B, s) : launch_g16_pair_tile<2, 1, 1, 8>(a, B, s);
-  if (nwv == 8) return a.C == 32 ? launch_g16_pair_tile<1, 2, 3, 8>(a, B, s) : launch_g16_pair_tile<2, 1, 3, 8>(a, B, s);
+  // round 3: TWO ring slots of twice the taps (32 channels: 4 taps = 16 KB, 64 channels: 2 taps = 16 KB; 72 KB of LDS
+  // per block, still two blocks per CU): the slice hand-over -- counted wait, barrier, LDS-DMA issue: 0.5 us per slice
+  // in the stamps of profiles/r03_pair_kernel_phase_stamps.txt, more than the slice's MFMAs -- happens half as often
+  // (generator -1.2 ms same box; the request is only one slice ahead now, which gives part of it back)
+  if (nwv == 8) return a.C == 32 ? launch_g16_pair_tile<1, 4, 3, 8, 2>(a, B, s) : launch_g16_pair_tile<2, 2, 3, 8, 2>(a, B, s);
 #ifdef VSP_EXPERIMENTS
   return a.C == 32 ? launch_g16_pair_tile<1, 2, 3, 16>(a, B, s) : launch_g16_pair_tile<2, 1, 3, 16>(a, B, s);
 #else
