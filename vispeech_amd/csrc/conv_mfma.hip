@@ -21,6 +21,7 @@
 // models.py:119-133, 271-290, 526-529; frame_prior_network.py:50-55.
 #include "kernels.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -106,6 +107,181 @@ __device__ __forceinline__ void conv_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 constexpr int conv_ring_slots(int MT, int WM) { return 3; }   // (four slots for the 8 KiB steps measured slower: 57 KiB per block = two blocks per CU instead of three)
+
+// Plain (non-polyphase) store of a block's accumulators, shared by the frame-rate kernels below, in two halves: every
+// operand the epilogue reads (bias and conditioning rows, the residual, the accumulate-into destination) is loaded into
+// ConvEpi by conv_epi_load -- the latency kernel does that FIRST, so that the loads' round trip runs under its main loop
+// -- and conv_epi_store does the arithmetic and the stores.  A lane owns 16 rows of a tile as four groups of four
+// CONSECUTIVE rows (8 g + 4 h + 0..3): bias / conditioning come as one 16-byte load per group, addresses are 32-bit
+// offsets into buffer descriptors, and every predicate (row < M, column < Nq, operand present) selects the
+// out-of-range offset instead of a branch (loads give 0, stores are dropped).
+template <int MT, int NT>
+struct ConvEpi {
+  float bv[MT][16], cv[MT][16];          // bias / conditioning of the lane's rows
+  unsigned rv[MT][NT][16], pv[MT][NT][16];   // residual, previous value of the destination
+};
+constexpr int CONV_OOR = 0x7ffffff0;
+
+template <int MT, int NT>
+__device__ __forceinline__ void conv_epi_load(const ConvArgs& a, ConvEpi<MT, NT>& e, int mtile0, int n_mtiles, int t0, int wn,
+                                              int l31, int h, int b) {
+  const float* resb = a.res ? a.res + (size_t)b * a.r_bs : nullptr;
+  float* outb = a.out + (size_t)b * a.o_bs;
+  const float* condb = a.cond ? a.cond + (size_t)b * a.cond_bs : nullptr;
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(outb, 0, CONV_OOR, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(resb ? resb : outb), 0, CONV_OOR, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro2 = __builtin_amdgcn_make_buffer_rsrc(
+      a.split_row ? a.out2 + (size_t)b * a.o2_bs : outb, 0, CONV_OOR, 0x00020000);
+  auto row_vec = [&](const float* p, int row0, float* v) {     // p[row0 .. row0 + 3], rows >= M read as 0
+    v[0] = v[1] = v[2] = v[3] = 0.f;
+    if (!p) return;
+    if (row0 + 3 < a.M && (reinterpret_cast<uintptr_t>(p + row0) & 15) == 0) {
+      const float4 t = *reinterpret_cast<const float4*>(p + row0);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (row0 + i < a.M) v[i] = p[row0 + i];
+    }
+  };
+  const bool gate_ep = a.act == 2;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int mtile = mtile0 + mt;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      row_vec(a.bias, mtile * 32 + 8 * g + 4 * h, &e.bv[mt][4 * g]);
+      row_vec(condb, mtile * 32 + 8 * g + 4 * h, &e.cv[mt][4 * g]);
+    }
+    const bool second = a.split_row && mtile * 32 >= a.split_row;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int q = t0 + (wn * NT + nt) * 32 + l31;
+      const bool qin = q < a.Nq && !gate_ep && mtile < n_mtiles;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = mtile * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+        const bool st = qin && row < a.M;
+        const int oo = st ? (row * (int)a.o_cs + q) * 4 : CONV_OOR;
+        const int oo2 = st ? ((row - a.split_row) * (int)a.o2_cs + q) * 4 : CONV_OOR;
+        // (uniform branches: a launch without a residual / an accumulating destination issues none of these)
+        e.rv[mt][nt][r] = 0u;
+        e.pv[mt][nt][r] = 0u;
+        if (resb && !second) e.rv[mt][nt][r] = __builtin_amdgcn_raw_buffer_load_b32(rr, st ? (row * (int)a.r_cs + q) * 4 : CONV_OOR, 0, 0);
+        if (a.acc_prev && !second) e.pv[mt][nt][r] = __builtin_amdgcn_raw_buffer_load_b32(ro, oo, 0, 0);
+        if (a.acc_prev2 && second) e.pv[mt][nt][r] = __builtin_amdgcn_raw_buffer_load_b32(ro2, oo2, 0, 0);
+      }
+    }
+  }
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void conv_epi_store(const ConvArgs& a, f32x16 (&acc)[MT][NT], const ConvEpi<MT, NT>& e, int mtile0,
+                                               int n_mtiles, int t0, int wn, int l31, int h, int b, int len) {
+  float* outb = a.out + (size_t)b * a.o_bs;
+  const bool has_cond = a.cond != nullptr, has_res = a.res != nullptr;
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(outb, 0, CONV_OOR, 0x00020000);
+  if (a.act == 2) {
+    // WN gate (reference commons.py:100-107): tiles (2i, 2i+1) hold the tanh / sigmoid halves.
+    if constexpr (MT % 2 == 0) {
+#pragma unroll
+      for (int mp = 0; mp < MT / 2; ++mp) {
+        const int mtile = mtile0 + 2 * mp;
+        if (mtile + 1 >= n_mtiles) continue;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int q = t0 + (wn * NT + nt) * 32 + l31;
+          const bool qin = q < a.Nq, valid = q < len;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int g = r >> 2, i = r & 3;
+            float va = acc[2 * mp][nt][r], vb = acc[2 * mp + 1][nt][r];
+            if (a.bias) { va += e.bv[2 * mp][r]; vb += e.bv[2 * mp + 1][r]; }
+            if (has_cond) { va += e.cv[2 * mp][r]; vb += e.cv[2 * mp + 1][r]; }
+            float v = tanhf(va) * (1.f / (1.f + expf(-vb)));
+            if (a.mask_post && !valid) v = 0.f;
+            const int orow = (mtile >> 1) * 32 + 8 * g + 4 * h + i;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro, qin ? (orow * (int)a.o_cs + q) * 4 : CONV_OOR, 0, 0);
+          }
+        }
+      }
+    }
+    return;
+  }
+  const __amdgpu_buffer_rsrc_t ro2 = __builtin_amdgcn_make_buffer_rsrc(
+      a.split_row ? a.out2 + (size_t)b * a.o2_bs : outb, 0, CONV_OOR, 0x00020000);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int mtile = mtile0 + mt;
+    if (mtile >= n_mtiles) continue;
+    if (a.split_row && mtile * 32 >= a.split_row) {
+      // second destination: out2[row - split_row] = conv + bias (+ out2)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int q = t0 + (wn * NT + nt) * 32 + l31;
+        const bool qin = q < a.Nq, keep = !a.mask_post2 || q < len;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = mtile * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+          float v = acc[mt][nt][r];
+          if (a.bias) v += e.bv[mt][r];
+          if (a.acc_prev2) v += __uint_as_float(e.pv[mt][nt][r]);
+          if (!keep) v = 0.f;
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro2,
+                                                (qin && row < a.M) ? ((row - a.split_row) * (int)a.o2_cs + q) * 4 : CONV_OOR, 0, 0);
+        }
+      }
+      continue;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int q = t0 + (wn * NT + nt) * 32 + l31;
+      const bool qin = q < a.Nq, valid = q < len;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = mtile * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+        float v = acc[mt][nt][r];
+        if (a.bias) v += e.bv[mt][r];
+        if (has_cond) v += e.cv[mt][r];
+        if (a.act == 1) v = fmaxf(v, 0.f);
+        if (a.mask_pre && !valid) v = 0.f;
+        if (a.alpha != 1.f) v *= a.alpha;
+        if (has_res) v += __uint_as_float(e.rv[mt][nt][r]);
+        if (a.acc_prev) v += __uint_as_float(e.pv[mt][nt][r]);
+        if (a.div != 1.f) v /= a.div;
+        if (a.mask_post && !valid) v = 0.f;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro, (qin && row < a.M) ? (row * (int)a.o_cs + q) * 4 : CONV_OOR, 0, 0);
+      }
+    }
+  }
+}
+
+// (the throughput kernel, at two blocks per CU: one tile -- for the gate, one pair of tiles -- at a time)
+template <int S, int MT, int NT>
+__device__ __forceinline__ void conv_store_slices(const ConvArgs& a, f32x16 (&acc)[MT][NT], int mtile0, int n_mtiles, int t0,
+                                                  int wn, int l31, int h, int b, int len) {
+#pragma unroll
+  for (int ms = 0; ms < MT / S; ++ms)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      f32x16 t[S][1];
+#pragma unroll
+      for (int u = 0; u < S; ++u) t[u][0] = acc[S * ms + u][nt];
+      ConvEpi<S, 1> e;
+      const int tq = t0 + (wn * NT + nt) * 32;
+      conv_epi_load<S, 1>(a, e, mtile0 + S * ms, n_mtiles, tq, 0, l31, h, b);
+      conv_epi_store<S, 1>(a, t, e, mtile0 + S * ms, n_mtiles, tq, 0, l31, h, b, len);
+    }
+}
+template <int MT, int NT>
+__device__ __forceinline__ void conv_store_plain(const ConvArgs& a, f32x16 (&acc)[MT][NT], int mtile0, int n_mtiles, int t0,
+                                                 int wn, int l31, int h, int b, int len) {
+  if (a.act == 2) {
+    if constexpr (MT % 2 == 0) conv_store_slices<2, MT, NT>(a, acc, mtile0, n_mtiles, t0, wn, l31, h, b, len);
+  } else {
+    conv_store_slices<1, MT, NT>(a, acc, mtile0, n_mtiles, t0, wn, l31, h, b, len);
+  }
+}
 
 template <int MT, int NT, int WM, int WN, bool F16S, bool RING = false>
 __global__ void __launch_bounds__(64 * WM * WN, F16S ? 2 : 1) conv1d_f32_mfma(ConvArgs a) {
@@ -477,130 +653,7 @@ __global__ void __launch_bounds__(64 * WM * WN, F16S ? 2 : 1) conv1d_f32_mfma(Co
   float* outb = a.out + (size_t)b * a.o_bs;
   const float* condb = a.cond ? a.cond + (size_t)b * a.cond_bs : nullptr;
   if (a.ups_s == 0) {
-    // Plain (non-polyphase) store, the form every frame-rate convolution takes.  A lane owns 16 rows of a tile as four
-    // groups of four CONSECUTIVE rows (8 g + 4 h + 0..3): bias / conditioning come as one 16-byte load per group,
-    // addresses are 32-bit offsets into buffer descriptors, and every predicate (row < M, column < Nq, operand
-    // present) selects the out-of-range offset instead of a branch (loads give 0, stores are dropped).
-    constexpr int OOR = 0x7ffffff0;
-    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(outb, 0, OOR, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(resb ? resb : outb), 0, OOR, 0x00020000);
-    const bool gate_ep = a.act == 2;
-    auto row_vec = [&](const float* p, int row0, float (&v)[4]) {     // p[row0 .. row0 + 3], rows >= M read as 0
-      v[0] = v[1] = v[2] = v[3] = 0.f;
-      if (!p) return;
-      if (row0 + 3 < a.M && (reinterpret_cast<uintptr_t>(p + row0) & 15) == 0) {
-        const float4 t = *reinterpret_cast<const float4*>(p + row0);
-        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (row0 + i < a.M) v[i] = p[row0 + i];
-      }
-    };
-    if (gate_ep) {
-      // WN gate (reference commons.py:100-107): tiles (2i, 2i+1) hold the tanh / sigmoid halves.
-      if constexpr (MT % 2 == 0) {
-#pragma unroll
-        for (int mp = 0; mp < MT / 2; ++mp) {
-          const int mtile = mtile0 + 2 * mp;
-          if (mtile + 1 >= n_mtiles) continue;
-          float ba[4][4], bb[4][4], ca[4][4], cb[4][4];
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            row_vec(a.bias, mtile * 32 + 8 * g + 4 * h, ba[g]);
-            row_vec(a.bias, mtile * 32 + 32 + 8 * g + 4 * h, bb[g]);
-            row_vec(condb, mtile * 32 + 8 * g + 4 * h, ca[g]);
-            row_vec(condb, mtile * 32 + 32 + 8 * g + 4 * h, cb[g]);
-          }
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            const int q = t0 + (wn * NT + nt) * 32 + l31;
-            const bool qin = q < a.Nq, valid = q < len;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int g = r >> 2, i = r & 3;
-              float va = acc[2 * mp][nt][r], vb = acc[2 * mp + 1][nt][r];
-              if (a.bias) { va += ba[g][i]; vb += bb[g][i]; }
-              if (condb) { va += ca[g][i]; vb += cb[g][i]; }
-              float v = tanhf(va) * (1.f / (1.f + expf(-vb)));
-              if (a.mask_post && !valid) v = 0.f;
-              const int orow = (mtile >> 1) * 32 + 8 * g + 4 * h + i;
-              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro, qin ? (orow * (int)a.o_cs + q) * 4 : OOR, 0, 0);
-            }
-          }
-        }
-      }
-      return;
-    }
-    const __amdgpu_buffer_rsrc_t ro2 = __builtin_amdgcn_make_buffer_rsrc(
-        a.split_row ? a.out2 + (size_t)b * a.o2_bs : outb, 0, OOR, 0x00020000);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int mtile = mtile0 + mt;
-      if (mtile >= n_mtiles) continue;
-      float bv[4][4], cv[4][4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        row_vec(a.bias, mtile * 32 + 8 * g + 4 * h, bv[g]);
-        row_vec(condb, mtile * 32 + 8 * g + 4 * h, cv[g]);
-      }
-      if (a.split_row && mtile * 32 >= a.split_row) {
-        // second destination: out2[row - split_row] = conv + bias (+ out2)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const int q = t0 + (wn * NT + nt) * 32 + l31;
-          const bool qin = q < a.Nq, keep = !a.mask_post2 || q < len;
-          int oo[16];
-          unsigned pv[16];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = mtile * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-            oo[r] = (qin && row < a.M) ? ((row - a.split_row) * (int)a.o2_cs + q) * 4 : OOR;
-            pv[r] = __builtin_amdgcn_raw_buffer_load_b32(ro2, a.acc_prev2 ? oo[r] : OOR, 0, 0);
-          }
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float v = acc[mt][nt][r];
-            if (a.bias) v += bv[r >> 2][r & 3];
-            if (a.acc_prev2) v += __uint_as_float(pv[r]);
-            if (!keep) v = 0.f;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro2, oo[r], 0, 0);
-          }
-        }
-        continue;
-      }
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int q = t0 + (wn * NT + nt) * 32 + l31;
-        const bool qin = q < a.Nq, valid = q < len;
-        // all loads of the tile first (res / out_prev may alias out), then the arithmetic and the stores
-        int oo[16];
-        unsigned rv[16], pv[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = mtile * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-          const bool st = qin && row < a.M;
-          oo[r] = st ? (row * (int)a.o_cs + q) * 4 : OOR;
-          rv[r] = __builtin_amdgcn_raw_buffer_load_b32(rr, (st && resb) ? (row * (int)a.r_cs + q) * 4 : OOR, 0, 0);
-          pv[r] = __builtin_amdgcn_raw_buffer_load_b32(ro, a.acc_prev ? oo[r] : OOR, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int g = r >> 2, i = r & 3;
-          float v = acc[mt][nt][r];
-          if (a.bias) v += bv[g][i];
-          if (condb) v += cv[g][i];
-          if (a.act == 1) v = fmaxf(v, 0.f);
-          if (a.mask_pre && !valid) v = 0.f;
-          if (a.alpha != 1.f) v *= a.alpha;
-          if (resb) v += __uint_as_float(rv[r]);
-          if (a.acc_prev) v += __uint_as_float(pv[r]);
-          if (a.div != 1.f) v /= a.div;
-          if (a.mask_post && !valid) v = 0.f;
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro, oo[r], 0, 0);
-        }
-      }
-    }
+    conv_store_plain<MT, NT>(a, acc, mtile0, n_mtiles, t0, wn, l31, h, b, len);
     return;
   }
   if (a.act == 2) {
@@ -681,6 +734,408 @@ __global__ void __launch_bounds__(64 * WM * WN, F16S ? 2 : 1) conv1d_f32_mfma(Co
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// conv_frame_f16s: the LATENCY form of the split-f16 ring kernel above, for grids that do not fill the chip (one utterance,
+// or one long one: a few dozen blocks whose K loop is a chain of dependent steps).  There a launch costs
+// (steps) x (what a step serialises), and in-kernel stamps of the kernel above put a step at 0.5-0.8 us against 0.16 us
+// of matrix issue: a counted wait and a barrier per tap with the fragment reads exposed behind it, ~1 us of conversion
+// per chunk on the critical path, the epilogue's two dependent memory round trips (5-6 us) at the end.  Same tiles,
+// fragments, packing and epilogue arithmetic; what differs:
+//   * the tap count K is a template parameter and the unit of synchronisation is an ITERATION of G chunks (G K steps):
+//     one counted wait and one barrier per iteration, its taps unrolled behind it (fragment reads of a tap run under the
+//     MFMAs of the tap before);
+//   * no window data in registers: the fp32 window of a chunk is copied by LDS-DMA into a window slot, WI - 1 iterations
+//     ahead, laid out so that the two 16-byte pieces a lane converts -- four times of channels 2p and 2p+1 -- sit exactly
+//     where that lane's hi and lo image words go: the conversion (mask, leaky-relu, truncating split) is IN PLACE, one
+//     iteration ahead of its use;
+//   * the weights of an iteration are copied RI - 1 iterations ahead into a ring of RI iteration slots;
+//   * every operand of the epilogue is requested before anything else: its round trip runs under the main loop.
+// Every wait is a counted vmcnt: the copies of a wave complete in issue order, and the number issued behind the one
+// waited for is known (the issue order is W(0..RI-2), X(0..WI-2), then per iteration i: W(i+RI-1), X(i+WI-1)).
+constexpr int FR_HALO = 12;        // K > 1: LWP = BN + FR_HALO >= BN + (K-1) dil + 3 (alignment) + 3 (float4 round-up)
+
+// s_waitcnt vmcnt(n) for a wave-uniform n (the instruction takes an immediate); n above the 6-bit field waits for 63
+#define FR_VM1(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+#define FR_VM8(a, b, c, d, e, f, g, h) FR_VM1(a) FR_VM1(b) FR_VM1(c) FR_VM1(d) FR_VM1(e) FR_VM1(f) FR_VM1(g) FR_VM1(h)
+#ifndef FR_DIAG
+#define FR_DIAG 0          // timing-only ablations (results wrong): 1 no MFMA, 2 no counted waits, 4 no conversion, 8 no window copies
+#endif
+__device__ __forceinline__ void fr_vmcnt(int n) {
+  if constexpr ((FR_DIAG & 2) != 0) return;
+  switch (n) {
+    FR_VM8(0, 1, 2, 3, 4, 5, 6, 7) FR_VM8(8, 9, 10, 11, 12, 13, 14, 15) FR_VM8(16, 17, 18, 19, 20, 21, 22, 23)
+    FR_VM8(24, 25, 26, 27, 28, 29, 30, 31) FR_VM8(32, 33, 34, 35, 36, 37, 38, 39) FR_VM8(40, 41, 42, 43, 44, 45, 46, 47)
+    FR_VM8(48, 49, 50, 51, 52, 53, 54, 55) FR_VM8(56, 57, 58, 59, 60, 61, 62, 63)
+    default: asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
+  }
+}
+// FR_STAMPS (diagnostic build, tools/stamps_frame.py): wave 0 of every block of the VSP_STAMP_FRAME-th conv_frame_f16s
+// launch records tagged wall-clock stamps (s_memrealtime, 100 MHz): 1 start | 2 requests out | 3 first window in |
+// 4 first window converted | per iteration: 10 top, 11 waited, 12 barrier, 13 copies issued, 14 MFMAs issued, 15 next
+// windows converted | 30 loop done | 31 stores issued | 32 retired.
+#ifdef FR_STAMPS
+constexpr int FR_NSTAMP = 512, FR_NSAMPLE = 64;
+__device__ unsigned long long g_fr_stamps[FR_NSAMPLE][FR_NSTAMP];
+__device__ unsigned g_fr_stamp_count;
+__device__ int g_fr_stamp_on;
+#define FR_STAMPT(tag)                                                                  \
+  do {                                                                                  \
+    if (stamp_slot >= 0 && stamp_n < FR_NSTAMP && lane == 0)                            \
+      g_fr_stamps[stamp_slot][stamp_n] = (__builtin_amdgcn_s_memrealtime() & 0x00ffffffffffffffull) | ((unsigned long long)(tag) << 56); \
+    ++stamp_n;                                                                          \
+  } while (0)
+extern "C" int vsp_debug_stamps_frame(unsigned long long* host, int max_samples, int reset) {
+  unsigned n = 0;
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_fr_stamp_count), sizeof n);
+  if ((int)n > max_samples) n = max_samples;
+  if (n > (unsigned)FR_NSAMPLE) n = FR_NSAMPLE;
+  (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fr_stamps), (size_t)n * FR_NSTAMP * sizeof(unsigned long long));
+  if (reset) { const unsigned z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fr_stamp_count), &z, sizeof z); }
+  return (int)n;
+}
+#else
+#define FR_STAMPT(tag) ((void)0)
+#endif
+#if FR_DIAG & 1
+#define FR_MFMA16(a, b, c) ([&]() { asm volatile("" ::"v"(a), "v"(b)); return c; }())
+#else
+#define FR_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#endif
+
+template <int MT, int NT, int WM, int WN, int K, int G, int RI, int WI>
+__global__ void __launch_bounds__(64 * WM * WN, 1) conv_frame_f16s(ConvArgs a) {
+  constexpr int HALO = K == 1 ? 0 : FR_HALO;                    // (a 1x1 has no halo and no padding: its window is aligned)
+  constexpr int BN = 32 * NT * WN, LWP = BN + HALO, LWP4 = LWP / 4, NW = WM * WN;
+  constexpr int SB = MT * WM * 4096, PW = MT * WM * 4 / NW;     // bytes of one step's weights; 1 KiB pieces per wave and step
+  constexpr int SI = G * K;                                     // steps of an iteration
+  constexpr int NF4 = CONV_CK * LWP4;                           // 16-byte positions of a window slot: hi image | lo image
+  constexpr int NPF = (NF4 + 64 * NW - 1) / (64 * NW);          // 1 KiB window pieces per wave and chunk
+  constexpr int WSLOT = NPF * NW * 1024;                        // bytes of a window slot
+  constexpr int RWPF = (CONV_CK / 2) / NW;                      // channel pairs a wave converts
+  static_assert((MT * WM * 4) % NW == 0 && (CONV_CK / 2) % NW == 0, "pieces and channel pairs divide over the waves");
+  static_assert(LWP % 4 == 0 && LWP4 <= 64, "one conversion sweep");
+  static_assert(WI >= 3 && RI >= 2, "a window is converted one iteration after it landed, one before its use");
+  extern __shared__ __attribute__((aligned(16))) float xs[];
+  char* const wbase = reinterpret_cast<char*>(xs);
+  char* const ring = wbase + WI * G * WSLOT;
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int b = blockIdx.z;
+  const int t0 = blockIdx.x * BN;
+  const int mtile0 = (blockIdx.y * WM + wm) * MT;
+  const int n_mtiles = (a.M + 31) >> 5;
+  const int nch = a.nchunks, n_iter = (nch + G - 1) / G;
+  const int total_it = nch * K;
+#ifdef FR_STAMPS
+  int stamp_slot = -1, stamp_n = 0;
+  if (wave == 0 && g_fr_stamp_on) {
+    unsigned sl_ = 0;
+    if (lane == 0) sl_ = atomicAdd(&g_fr_stamp_count, 1u);
+    sl_ = __builtin_amdgcn_readfirstlane(sl_);
+    stamp_slot = sl_ < (unsigned)FR_NSAMPLE ? (int)sl_ : -1;
+  }
+  FR_STAMPT(1);
+#endif
+  // the epilogue's operands first: older than every copy below, they never enter the counted waits
+  ConvEpi<MT, NT> epi;
+  conv_epi_load<MT, NT>(a, epi, mtile0, n_mtiles, t0, wn, l31, h, b);
+  FR_STAMPT(5);
+
+  const float4* wp4 = reinterpret_cast<const float4*>(a.wp);
+  // weights of iteration j -> ring slot j % RI: step (g, tap) of the iteration at (g K + tap) SB
+  auto w_dma = [&](int j) {
+    char* const dst0 = ring + (j % RI) * (SI * SB);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int c = j * G + g;
+      if (c >= nch) break;
+#pragma unroll
+      for (int tap = 0; tap < K; ++tap) {
+#pragma unroll
+        for (int u = 0; u < PW; ++u) {
+          const int p = u * NW + wave;
+          int mtile = blockIdx.y * (WM * MT) + (p >> 2);
+          mtile = mtile < n_mtiles ? mtile : n_mtiles - 1;     // (m-tiles past the last re-read it: never stored)
+          const float4* src = wp4 + (((size_t)mtile * total_it + c * K + tap) * (CONV_CK / 8) + (p & 3)) * 64 + lane;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)(dst0 + (g * K + tap) * SB + p * 1024), 16, 0, 0);
+        }
+      }
+    }
+  };
+  // window geometry (16-byte aligned rows: the launcher checks)
+  const float* xb = a.x + (size_t)b * a.x_bs;
+  const int LW = BN + (K - 1) * a.dil;
+  const int t_start = ((t0 - a.pad) >> 2) << 2;
+  const int off = (t0 - a.pad) - t_start;
+  const int LW4 = (LW + off + 3) >> 2;
+  // piece u of a chunk's window, lane l -> slot position g = (u NW + wave) 64 + l = (image, pair row p, four times c4):
+  // channel 2p + image of the chunk.  Positions outside the window (and channels past Cin) copy x[b][0][0..3]: the
+  // conversion zeroes what is not there.
+  long woff[NPF];
+  int wch[NPF];
+#pragma unroll
+  for (int u = 0; u < NPF; ++u) {
+    const int g = (u * NW + wave) * 64 + lane;
+    const int img = g / (16 * LWP4), p = (g / LWP4) % 16, c4 = g % LWP4;
+    const int t = t_start + 4 * c4;
+    const bool ok = g < NF4 && c4 < LW4 && t >= 0 && t < a.T_in;
+    wch[u] = ok ? 2 * p + img : 0x40000000;
+    woff[u] = (long)(2 * p + img) * a.x_cs + t;
+  }
+  auto x_dma = [&](int j) {
+    if constexpr ((FR_DIAG & 8) != 0) return;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int c = j * G + g;
+      if (c >= nch) break;
+      char* const dst = wbase + ((j % WI) * G + g) * WSLOT;
+#pragma unroll
+      for (int u = 0; u < NPF; ++u) {
+        const bool ok = c * CONV_CK + wch[u] < a.Cin;
+        const float* src = ok ? xb + (size_t)c * CONV_CK * a.x_cs + woff[u] : xb;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(dst + (u * NW + wave) * 1024), 16, 0, 0);
+      }
+    }
+  };
+  // requests: weights of the first RI - 1 iterations, windows of the first WI - 1
+#pragma unroll
+  for (int j = 0; j < RI - 1; ++j) w_dma(j);
+  FR_STAMPT(6);
+#pragma unroll
+  for (int j = 0; j < WI - 1; ++j) x_dma(j);
+  FR_STAMPT(2);
+
+  // in-place prologue of the conv (mask, leaky-relu as max(x, slope x)) and truncating split (gen16.hip: g16_split2) of
+  // the four times x two channels of a lane: fp32 rows 2p | 2p+1 in, hi | lo image words out, the same two 16-byte places
+  const int len = a.lengths ? (int)a.lengths[b] : 0x7fffffff;
+  const int t4 = t_start + 4 * lane;
+  const bool tin = lane < LW4 && t4 >= 0 && t4 < a.T_in;
+  const int lim = a.in_mask ? (len < a.T_in ? len : a.T_in) : a.T_in;
+  const bool tfull = tin && t4 + 3 < lim;
+  const float slope_eff = a.in_act ? a.in_slope : 1.f;
+  // (a block whose whole window lies inside the valid times, on a full chunk of channels, with no activation -- most
+  // blocks of most launches -- has nothing to mask or clamp: the conversion is then six instructions per column pair)
+  const bool win_inside = t_start >= 0 && t_start + 4 * LW4 <= lim;
+  typedef float f32x2v __attribute__((ext_vector_type(2)));
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  auto convert = [&](int j) {                 // the windows of iteration j
+    if constexpr ((FR_DIAG & 4) != 0) return;
+    if (lane >= LW4) return;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int chunk = j * G + g;
+      if (chunk >= nch) break;
+      char* const slot = wbase + ((j % WI) * G + g) * WSLOT;
+      f32x4v va[RWPF], vb[RWPF];
+#pragma unroll
+      for (int q = 0; q < RWPF; ++q) {
+        const int p = wave + q * NW;
+        va[q] = *reinterpret_cast<const f32x4v*>(slot + (p * LWP4 + lane) * 16);
+        vb[q] = *reinterpret_cast<const f32x4v*>(slot + ((16 + p) * LWP4 + lane) * 16);
+      }
+      const bool plain = win_inside && (chunk + 1) * CONV_CK <= a.Cin && slope_eff == 1.f;
+#pragma unroll
+      for (int q = 0; q < RWPF; ++q) {
+        const int p = wave + q * NW;
+        unsigned wh4[4], wl4[4];
+        if (plain) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const f32x2v x = {va[q][u], vb[q][u]};
+            const f32x2v hf = {__uint_as_float(__float_as_uint(x.x) & 0xffffe000u), __uint_as_float(__float_as_uint(x.y) & 0xffffe000u)};
+            const f32x2v lf = (x - hf) * 2048.f;
+            wh4[u] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(hf.x, hf.y));
+            wl4[u] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lf.x, lf.y));
+          }
+        } else {
+          const int ci = chunk * CONV_CK + 2 * p;
+          const bool ina = tin && ci < a.Cin, inb = tin && ci + 1 < a.Cin;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            f32x2v x = {va[q][u], vb[q][u]};
+            if (!(tfull && inb)) {                          // window edge / ragged channel count: zero what is not there
+              x.x = (ina && t4 + u < lim) ? x.x : 0.f;
+              x.y = (inb && t4 + u < lim) ? x.y : 0.f;
+            }
+            const f32x2v y = x * slope_eff;
+            asm("v_max_f32 %0, %1, %2" : "=v"(x.x) : "v"(x.x), "v"(y.x));
+            asm("v_max_f32 %0, %1, %2" : "=v"(x.y) : "v"(x.y), "v"(y.y));
+            const f32x2v hf = {__uint_as_float(__float_as_uint(x.x) & 0xffffe000u), __uint_as_float(__float_as_uint(x.y) & 0xffffe000u)};
+            const f32x2v lf = (x - hf) * 2048.f;
+            wh4[u] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(hf.x, hf.y));
+            wl4[u] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lf.x, lf.y));
+          }
+        }
+        *reinterpret_cast<u32x4*>(slot + (p * LWP4 + lane) * 16) = u32x4{wh4[0], wh4[1], wh4[2], wh4[3]};
+        *reinterpret_cast<u32x4*>(slot + ((16 + p) * LWP4 + lane) * 16) = u32x4{wl4[0], wl4[1], wl4[2], wl4[3]};
+      }
+    }
+  };
+  // copies a wave issues for iteration j (0 past the end): weights, windows
+  auto cin = [&](int j) { const int r = nch - j * G; return j < n_iter ? (r < G ? r : G) : 0; };
+  auto Wn = [&](int j) { return cin(j) * (K * PW); };
+  auto Xn = [&](int j) { return cin(j) * NPF; };
+
+  f32x16 acc[MT][NT], crs[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = crs[mt][nt][r] = 0.f;
+
+  {  // the first iteration's windows: behind them, the windows of iterations 1 .. WI - 2
+    int n = 0;
+#pragma unroll
+    for (int j = 1; j < WI - 1; ++j) n += Xn(j);
+    fr_vmcnt(n);
+  }
+  CONV_RAW_BARRIER();
+  FR_STAMPT(3);
+  convert(0);
+  FR_STAMPT(4);
+
+  for (int i = 0; i < n_iter; ++i) {
+    FR_STAMPT(10);
+    {
+      // my pieces of W(i) and, for the conversion below, of X(i + 1): the copies issued behind each
+      int nw = 0;
+      if (i <= RI - 2) {
+#pragma unroll
+        for (int j = 1; j < RI - 1; ++j) nw += j > i ? Wn(j) : 0;
+#pragma unroll
+        for (int j = 0; j < WI - 1; ++j) nw += Xn(j);
+        for (int j = 0; j < i; ++j) nw += Wn(j + RI - 1) + Xn(j + WI - 1);
+      } else {
+        const int j0 = i - RI + 1;
+        nw = Xn(j0 + WI - 1);
+#pragma unroll
+        for (int d = 1; d < RI - 1; ++d) nw += Wn(j0 + d + RI - 1) + Xn(j0 + d + WI - 1);      // j = j0 + 1 .. i - 1
+      }
+      int n = nw;
+      if (i + 1 < n_iter) {
+        int nx = 0;
+        if (i + 1 <= WI - 2) {
+#pragma unroll
+          for (int j = 2; j < WI - 1; ++j) nx += j > i + 1 ? Xn(j) : 0;
+          for (int j = 0; j < i; ++j) nx += Wn(j + RI - 1) + Xn(j + WI - 1);
+        } else {
+          const int j1 = i - WI + 2;
+#pragma unroll
+          for (int d = 1; d < WI - 2; ++d) nx += Wn(j1 + d + RI - 1) + Xn(j1 + d + WI - 1);    // j = j1 + 1 .. i - 1
+        }
+        n = nx < n ? nx : n;
+      }
+      fr_vmcnt(n);
+    }
+    FR_STAMPT(11);
+    CONV_RAW_BARRIER();            // this iteration's weights and converted windows are visible; iteration i - 1 is read out
+    FR_STAMPT(12);
+    w_dma(i + RI - 1);             // (into the slots iteration i - 1 was read from)
+    x_dma(i + WI - 1);
+    FR_STAMPT(13);
+    const char* const rbase = ring + (i % RI) * (SI * SB) + wm * (MT * 4096) + lane * 16;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if (i * G + g >= nch) break;
+      const unsigned* const ph = reinterpret_cast<const unsigned*>(wbase + ((i % WI) * G + g) * WSLOT);
+      const unsigned* const pl = ph + (CONV_CK / 2) * LWP;
+#pragma unroll
+      for (int tap = 0; tap < K; ++tap) {
+        const int col = wn * (NT * 32) + l31 + off + tap * a.dil;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          f16x8 bh[NT], bl[NT];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const unsigned* p = ph + (8 * ks + 4 * h) * LWP + col + nt * 32;
+            const unsigned* q = pl + (8 * ks + 4 * h) * LWP + col + nt * 32;
+            bh[nt] = __builtin_bit_cast(f16x8, u32x4{p[0], p[LWP], p[2 * LWP], p[3 * LWP]});
+            bl[nt] = __builtin_bit_cast(f16x8, u32x4{q[0], q[LWP], q[2 * LWP], q[3 * LWP]});
+          }
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const char* pa = rbase + (g * K + tap) * SB + mt * 4096 + ks * 2048;
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(pa);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(pa + 1024);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = FR_MFMA16(ah, bh[nt], acc[mt][nt]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) crs[mt][nt] = FR_MFMA16(ah, bl[nt], crs[mt][nt]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) crs[mt][nt] = FR_MFMA16(al, bh[nt], crs[mt][nt]);
+          }
+        }
+      }
+    }
+    FR_STAMPT(14);
+    if (i + 1 < n_iter) { convert(i + 1); FR_STAMPT(15); }
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] += crs[mt][nt][r] * (1.f / 2048.f);
+  FR_STAMPT(30);
+  conv_epi_store<MT, NT>(a, acc, epi, mtile0, n_mtiles, t0, wn, l31, h, b, len);
+#ifdef FR_STAMPS
+  FR_STAMPT(31);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  FR_STAMPT(32);
+#endif
+}
+
+#ifdef FR_STAMPS
+static int g_fr_launch_no = 0;
+static const int g_fr_on_vals[2] = {0, 1};
+#endif
+template <int MT, int NT, int WM, int WN, int K, int G, int RI, int WI>
+static hipError_t launch_frame(const ConvArgs& a, int B, hipStream_t s) {
+  constexpr int BN = 32 * NT * WN, BM = 32 * MT * WM, NW = WM * WN;
+  constexpr int NF4 = CONV_CK * ((BN + (K == 1 ? 0 : FR_HALO)) / 4);
+  constexpr size_t lds = (size_t)WI * G * ((NF4 + 64 * NW - 1) / (64 * NW)) * NW * 1024 + (size_t)RI * G * K * MT * WM * 4096;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  static bool attr_set = false;
+  auto kern = conv_frame_f16s<MT, NT, WM, WN, K, G, RI, WI>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  dim3 grid((a.Nq + BN - 1) / BN, (a.M + BM - 1) / BM, B);
+#ifdef FR_STAMPS
+  {  // stamps only in the VSP_STAMP_FRAME-th launch (0-based, counted over all conv_frame_f16s launches)
+    static int target = -2;
+    if (target == -2) { const char* e = getenv("VSP_STAMP_FRAME"); target = e ? atoi(e) : -1; }
+    const int on = g_fr_launch_no++ == target ? 1 : 0;
+    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_fr_stamp_on), &g_fr_on_vals[on], sizeof(int), 0, hipMemcpyHostToDevice, s);
+    if (on) fprintf(stderr, "[stamps] conv_frame_f16s<%d,%d,%d,%d,K%d,G%d,%d,%d> M %d Cin %d Nq %d grid %u x %u x %u\n", MT, NT, WM, WN, K,
+                    G, RI, WI, a.M, a.Cin, a.Nq, grid.x, grid.y, grid.z);
+  }
+#endif
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, a);
+  return hipGetLastError();
+}
+// the latency form for a tile shape, by tap count (other tap counts: the throughput kernel)
+template <int MT, int NT, int WM, int WN>
+static bool launch_frame_k(const ConvArgs& a, int B, hipStream_t s, hipError_t& e) {
+  constexpr int NW = WM * WN;
+  switch (a.K) {
+    case 1: e = launch_frame<MT, NT, WM, WN, 1, 2, 3, 3>(a, B, s); return true;
+    case 3: e = launch_frame<MT, NT, WM, WN, 3, 1, 3, 3>(a, B, s); return true;
+    case 5: e = launch_frame<MT, NT, WM, WN, 5, 1, 2, 3>(a, B, s); return true;
+    default: (void)NW; return false;
+  }
+}
+
 template <int MT, int NT, int WM, int WN, bool F16S = false, bool RING = false>
 static hipError_t launch_tile(const ConvArgs& a, int B, hipStream_t s) {
   constexpr int BN = 32 * NT * WN, BM = 32 * MT * WM;
@@ -700,6 +1155,20 @@ static hipError_t launch_tile(const ConvArgs& a, int B, hipStream_t s) {
   return hipGetLastError();
 }
 
+// Grids up to this many 64 x 128 tiles (two rounds of the chip at one block per CU) take the latency kernel; above it the
+// throughput kernel's three co-resident blocks per CU hide a block's serial steps better (C3, same box: 84.8 ms against
+// 88.8 with the latency kernel everywhere; one utterance 5.22 against 5.34 without it, the 5168-frame utterance 18.8
+// against 19.8).
+static long fr_max_blocks() {
+#ifdef VSP_EXPERIMENTS
+  static long v = -1;
+  if (v < 0) { const char* e = getenv("VSP_FR_BLOCKS"); v = e ? atol(e) : 512; }
+  return v;
+#else
+  return 512;
+#endif
+}
+
 hipError_t launch_conv(const ConvArgs& a, int B, hipStream_t s) {
   if ((a.K - 1) * a.dil + 3 > CONV_HALO || a.K < 1 || a.Nq <= 0 || B <= 0 || (a.split_row & 31) ||
       (a.split_row && (a.ups_s > 0 || a.act == 2 || !a.out2)))
@@ -714,6 +1183,15 @@ hipError_t launch_conv(const ConvArgs& a, int B, hipStream_t s) {
 #endif
   if (ring && a.f16s) {
     if (a.ups_s > 0) return hipErrorInvalidValue;
+    // the latency form (conv_frame_f16s) where the grid does not fill the chip: 64-row tiles, at most two rounds of blocks
+    const bool vec = ((a.x_cs & 3) == 0) && ((a.x_bs & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
+    const float sl = a.in_act ? a.in_slope : 1.f;
+    if (vec && (a.K - 1) * a.dil + 6 <= FR_HALO && (a.K > 1 || a.pad == 0) && sl >= 0.f && sl <= 1.f && (a.M > 32 || gate)) {
+      const long blocks = (long)B * ((a.Nq + 127) / 128) * ((a.M + 63) / 64);
+      hipError_t e = hipSuccess;
+      if (a.Nq <= 96) { if (blocks * 2 <= fr_max_blocks() && launch_frame_k<2, 1, 1, 2>(a, B, s, e)) return e; }
+      else if (blocks <= fr_max_blocks()) { if (launch_frame_k<2, 1, 1, 4>(a, B, s, e)) return e; }
+    }
     if (a.M <= 32 && !gate) {
       if (a.Nq >= 1024) return launch_tile<1, 4, 1, 4, true, true>(a, B, s);
       return launch_tile<1, 1, 1, 2, true, true>(a, B, s);
