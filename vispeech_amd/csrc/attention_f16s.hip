@@ -139,9 +139,12 @@ __global__ void __launch_bounds__(256) attn_pack_f16s(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Block = NWV waves, wave = NQ query tiles of 16.  Keys stream in tiles of 32 through two LDS buffers.
-template <int DK, int NWV, int NQ>
-__global__ void __launch_bounds__(64 * NWV) attn_relpos_f16s(const float* __restrict__ qkv, long bs, long cs,
+// Block = NWV x KS waves: NWV query groups of NQ query tiles of 16, each served by KS waves that take every KS-th key
+// tile (a second wave per SIMD hides the first one's MFMA / LDS / exp latencies, and a 5168-frame utterance is only 162
+// blocks of 64 queries); their (max, sum, O) partials are merged through LDS at the end.  Keys stream in tiles of 32
+// through two LDS buffers of KS tiles.
+template <int DK, int NWV, int NQ, int KS>
+__global__ void __launch_bounds__(64 * NWV * KS) attn_relpos_f16s(const float* __restrict__ qkv, long bs, long cs,
                                                             const _Float16* __restrict__ Qp, const _Float16* __restrict__ Kp,
                                                             const _Float16* __restrict__ Vp, const float* __restrict__ emb_k,
                                                             const float* __restrict__ emb_v,
@@ -152,14 +155,18 @@ __global__ void __launch_bounds__(64 * NWV) attn_relpos_f16s(const float* __rest
   constexpr int KTILE = 2 * NC * 2 * 1024;           // bytes of a 32-key K tile (2 key tiles x NC chunks x hi/lo)
   constexpr int VTILE = ND * 2 * 1024;               // bytes of a 32-key V tile
   constexpr int STAGE = KTILE + VTILE;
-  constexpr int NPIECE = STAGE / 1024, NPW = (NPIECE + NWV - 1) / NWV;
-  __shared__ __attribute__((aligned(16))) char kv[2 * STAGE];
+  constexpr int NWT = NWV * KS;                      // waves of the block
+  constexpr int NPIECE = KS * STAGE / 1024, NPW = (NPIECE + NWT - 1) / NWT;
+  constexpr int MERGE = (KS - 1) * NWV * NQ * (ND * 4 + 2) * 64 * 4;      // bytes of the partials handed over at the end
+  static_assert(MERGE <= 2 * KS * STAGE, "the partials reuse the key / value buffers");
+  __shared__ __attribute__((aligned(16))) char kv[2 * KS * STAGE];
   __shared__ float Rl[QB * AF_RS];                   // relative-key logits (2^x domain)
   __shared__ float Sb[QB * AF_RS];                   // raw band scores (2^x domain); -inf = no such key
   __shared__ float Evs[16 * DK];
 
   const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = wave_all % NWV, ks = wave_all / NWV;     // query group; which of the KS key-tile streams
   const int lane = tid & 63, l15 = lane & 15, q4 = lane >> 4;
   const int b = blockIdx.z, hd = blockIdx.y, i0 = blockIdx.x * QB;
   const int n_heads = gridDim.y;
@@ -171,17 +178,21 @@ __global__ void __launch_bounds__(64 * NWV) attn_relpos_f16s(const float* __rest
   const uint4* Vg = reinterpret_cast<const uint4*>(Vp + img);
   const int ntiles = (T + 31) / 32;
 
-  // ---- K / V tile t -> LDS buffer (t & 1) by LDS-DMA, 1 KiB pieces in fragment order
-  auto stage = [&](int t) {
-    char* dst = kv + (t & 1) * STAGE;
+  // ---- K / V tiles tt KS .. tt KS + KS - 1 -> LDS buffer (tt & 1) by LDS-DMA, 1 KiB pieces in fragment order
+  // (tiles past the last re-read it: nobody computes on them)
+  auto stage = [&](int tt) {
+    char* dst = kv + (tt & 1) * (KS * STAGE);
 #pragma unroll
     for (int u = 0; u < NPW; ++u) {
-      const int p = u * NWV + wave;
-      if (NPIECE % NWV == 0 || p < NPIECE) {
+      const int pp = u * NWT + wave_all;
+      if (NPIECE % NWT == 0 || pp < NPIECE) {
+        const int sub = pp / (STAGE / 1024), p = pp % (STAGE / 1024);
+        int t = tt * KS + sub;
+        t = t < ntiles ? t : ntiles - 1;
         const uint4* src = p < KTILE / 1024 ? Kg + ((size_t)t * (KTILE / 1024) + p) * 64 + lane
                                             : Vg + ((size_t)t * (VTILE / 1024) + (p - KTILE / 1024)) * 64 + lane;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(dst + pp * 1024), 16, 0, 0);
       }
     }
   };
@@ -200,20 +211,45 @@ __global__ void __launch_bounds__(64 * NWV) attn_relpos_f16s(const float* __rest
       Ql[n][c] = *reinterpret_cast<const f16x8*>(p + 64 * 8);
     }
 
-  // ---- relative-key logits of the block's queries (fp32, 2^x domain), band-score table, Ev
-  {
-    const float* qrow = qkv + (size_t)b * bs + (size_t)(hd * DK) * cs;
-    const float qs = AF_LOG2E / sqrtf((float)DK);
-    for (int idx = tid; idx < QB * nrel; idx += 64 * NWV) {
-      const int iq = idx % QB, r = idx / QB;
-      float sum = 0.f;
-      if (i0 + iq < T)
-        for (int d = 0; d < DK; ++d) sum += (qrow[(size_t)d * cs + i0 + iq] * qs) * emb_k[r * DK + d];
-      Rl[iq * AF_RS + r] = sum;
+  // ---- relative-key logits of the wave's queries (2^x domain): the 2w+1 rows of emb_k are 2w+1 more keys -- one S^T
+  // tile per query tile on the matrix core, split like the keys (round 2 did these T x (2w+1) x DK products as scalar
+  // fp32 loops over strided global reads: 15 % of the attention time on utterance-sized inputs) --, band-score table, Ev
+  if (ks == 0) {
+    f16x8 eh[NC], el[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = e0;
+      if (l15 < nrel) {
+        const float* pe = emb_k + (size_t)l15 * DK + c * 32 + q4 * 8;
+        e0 = *reinterpret_cast<const f32x4*>(pe);
+        e1 = *reinterpret_cast<const f32x4*>(pe + 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u += 2) {
+        f16x2 h2, l2;
+        af_split2(f32x2{e0[u] * AF_KS, e0[u + 1] * AF_KS}, h2, l2);
+        eh[c][u] = h2.x; eh[c][u + 1] = h2.y; el[c][u] = l2.x; el[c][u + 1] = l2.y;
+        af_split2(f32x2{e1[u] * AF_KS, e1[u + 1] * AF_KS}, h2, l2);
+        eh[c][4 + u] = h2.x; eh[c][5 + u] = h2.y; el[c][4 + u] = l2.x; el[c][5 + u] = l2.y;
+      }
     }
-    for (int idx = tid; idx < QB * AF_RS; idx += 64 * NWV) Sb[idx] = -INFINITY;
-    for (int idx = tid; idx < nrel * DK; idx += 64 * NWV) Evs[idx] = emb_v[idx];
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+      f32x4 R = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        R = __builtin_amdgcn_mfma_f32_16x16x32_f16(eh[c], Qh[n][c], R, 0, 0, 0);
+        R = __builtin_amdgcn_mfma_f32_16x16x32_f16(el[c], Qh[n][c], R, 0, 0, 0);
+        R = __builtin_amdgcn_mfma_f32_16x16x32_f16(eh[c], Ql[n][c], R, 0, 0, 0);
+      }
+      const int iq = (wave * NQ + n) * 16 + l15;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+        if (4 * q4 + jj < nrel) Rl[iq * AF_RS + 4 * q4 + jj] = R[jj] * (1.f / (AF_QS * AF_KS));
+    }
   }
+  for (int idx = tid; idx < QB * AF_RS; idx += 64 * NWT) Sb[idx] = -INFINITY;
+  for (int idx = tid; idx < nrel * DK; idx += 64 * NWT) Evs[idx] = emb_v[idx];
 
   f32x4 O[ND][NQ];
 #pragma unroll
@@ -226,11 +262,14 @@ __global__ void __launch_bounds__(64 * NWV) attn_relpos_f16s(const float* __rest
   const float s_unscale = 1.f / (AF_QS * AF_KS);
   const float masked = -1e4f * AF_LOG2E;
 
-  for (int t = 0; t < ntiles; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my pieces of tile t have landed
-    __syncthreads();                                      // everybody's have; everybody is done with tile t - 1
-    if (t + 1 < ntiles) stage(t + 1);
-    const char* kb = kv + (t & 1) * STAGE + lane * 16;
+  const int nsteps = (ntiles + KS - 1) / KS;
+  for (int tt = 0; tt < nsteps; ++tt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my pieces of step tt have landed
+    __syncthreads();                                      // everybody's have; everybody is done with step tt - 1
+    if (tt + 1 < nsteps) stage(tt + 1);
+    const int t = tt * KS + ks;                           // this wave's key tile of the step
+    if (t >= ntiles) continue;
+    const char* kb = kv + (tt & 1) * (KS * STAGE) + ks * STAGE + lane * 16;
     const char* vb = kb + KTILE;
     const int j0 = t * 32;
     // ---- S^T tiles: [key tile kt][query tile n], lane = query l15, register jj = key 16 kt + 4 q4 + jj
@@ -260,6 +299,14 @@ __global__ void __launch_bounds__(64 * NWV) attn_relpos_f16s(const float* __rest
       const int i = i0 + iq;
       const bool near = j0 + 31 >= i0 + (wave * NQ + n) * 16 - w && j0 <= i0 + (wave * NQ + n) * 16 + 15 + w;   // wave-uniform
       float sv[8];
+      // (wave-uniform: a tile away from the band whose 32 keys and 16 queries are all valid has nothing to add or mask)
+      const bool inside = !near && j0 + 31 < len && i0 + (wave * NQ + n) * 16 + 15 < len;
+      if (inside) {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) sv[4 * kt + jj] = S[kt][n][jj] * s_unscale;
+      } else
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -285,6 +332,7 @@ __global__ void __launch_bounds__(64 * NWV) attn_relpos_f16s(const float* __rest
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
       const float m_new = fmaxf(m_run[n], tmax);
       const float alpha = __builtin_amdgcn_exp2f(m_run[n] - m_new);
+      const bool moved = __builtin_amdgcn_ballot_w64(m_new != m_run[n]) != 0;     // (wave-uniform: did any query's running max move?)
       m_run[n] = m_new;
       float part = 0.f;
       f16x8 ph, pl;
@@ -300,8 +348,10 @@ __global__ void __launch_bounds__(64 * NWV) attn_relpos_f16s(const float* __rest
       l_run[n] = l_run[n] * alpha + part;
       Ph[n] = ph;
       Pl[n] = pl;
+      if (moved) {
 #pragma unroll
-      for (int dt = 0; dt < ND; ++dt) O[dt][n] *= alpha;
+        for (int dt = 0; dt < ND; ++dt) O[dt][n] *= alpha;
+      }
     }
     // ---- O^T += V^T P^T  (contraction over the tile's 32 keys in the packed order)
 #pragma unroll
@@ -316,7 +366,41 @@ __global__ void __launch_bounds__(64 * NWV) attn_relpos_f16s(const float* __rest
       }
     }
   }
-  __syncthreads();                                       // band scores of every wave are in Sb
+  __syncthreads();                                       // band scores of every wave are in Sb; the K / V buffers are free
+  if constexpr (KS > 1) {
+    // ---- the key-tile streams of a query group meet: (m, l, O) of streams 1 .. KS - 1 -> LDS -> stream 0
+    float* mg = reinterpret_cast<float*>(kv);
+    constexpr int NV = ND * 4 + 2;
+    if (ks > 0) {
+#pragma unroll
+      for (int n = 0; n < NQ; ++n) {
+        float* dst = mg + ((size_t)(((ks - 1) * NWV + wave) * NQ + n) * NV) * 64 + lane;
+        dst[0] = m_run[n];
+        dst[64] = l_run[n];
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) dst[(2 + dt * 4 + jj) * 64] = O[dt][n][jj];
+      }
+    }
+    __syncthreads();
+    if (ks > 0) return;
+#pragma unroll
+    for (int k2 = 1; k2 < KS; ++k2)
+#pragma unroll
+      for (int n = 0; n < NQ; ++n) {
+        const float* src = mg + ((size_t)(((k2 - 1) * NWV + wave) * NQ + n) * NV) * 64 + lane;
+        const float m2 = src[0], l2 = src[64];
+        const float m_new = fmaxf(m_run[n], m2);
+        const float a1 = __builtin_amdgcn_exp2f(m_run[n] - m_new), a2 = __builtin_amdgcn_exp2f(m2 - m_new);
+        m_run[n] = m_new;
+        l_run[n] = l_run[n] * a1 + l2 * a2;
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) O[dt][n][jj] = O[dt][n][jj] * a1 + src[(2 + dt * 4 + jj) * 64] * a2;
+      }
+  }
 
   // ---- normalise, add the relative-value term (fp32, from the final statistics), store
 #pragma unroll
@@ -345,13 +429,13 @@ __global__ void __launch_bounds__(64 * NWV) attn_relpos_f16s(const float* __rest
   }
 }
 
-template <int DK, int NWV, int NQ>
+template <int DK, int NWV, int NQ, int KS>
 static void launch_attn_f16s(const float* qkv, long qkv_bs, long qkv_cs, const _Float16* Qp, const _Float16* Kp,
                              const _Float16* Vp, const float* emb_k, const float* emb_v, const int64_t* lengths, float* out,
                              long o_bs, long o_cs, int B, int H, int n_heads, int T, int window, hipStream_t s) {
   constexpr int QB = 16 * NQ * NWV;
   dim3 grid((T + QB - 1) / QB, n_heads, B);
-  hipLaunchKernelGGL((attn_relpos_f16s<DK, NWV, NQ>), grid, dim3(64 * NWV), 0, s, qkv, qkv_bs, qkv_cs, Qp, Kp, Vp, emb_k,
+  hipLaunchKernelGGL((attn_relpos_f16s<DK, NWV, NQ, KS>), grid, dim3(64 * NWV * KS), 0, s, qkv, qkv_bs, qkv_cs, Qp, Kp, Vp, emb_k,
                      emb_v, lengths, out, o_bs, o_cs, H, T, window);
 }
 
@@ -370,8 +454,8 @@ hipError_t launch_attention_f16s(const float* qkv, long qkv_bs, long qkv_cs, con
   const bool small = (long)((T + 127) / 128) * n_heads * B < 512;
 #define VSP_ATTF(DKV)                                                                                                   \
   hipLaunchKernelGGL((attn_pack_f16s<DKV>), pgrid, dim3(256), 0, s, qkv, qkv_bs, qkv_cs, H, T, Qp, Kp, Vp);             \
-  if (small) launch_attn_f16s<DKV, 4, 1>(qkv, qkv_bs, qkv_cs, Qp, Kp, Vp, emb_k, emb_v, lengths, out, o_bs, o_cs, B, H, n_heads, T, window, s); \
-  else launch_attn_f16s<DKV, 4, 2>(qkv, qkv_bs, qkv_cs, Qp, Kp, Vp, emb_k, emb_v, lengths, out, o_bs, o_cs, B, H, n_heads, T, window, s)
+  if (small) launch_attn_f16s<DKV, 4, 1, 2>(qkv, qkv_bs, qkv_cs, Qp, Kp, Vp, emb_k, emb_v, lengths, out, o_bs, o_cs, B, H, n_heads, T, window, s); \
+  else launch_attn_f16s<DKV, 4, 2, 1>(qkv, qkv_bs, qkv_cs, Qp, Kp, Vp, emb_k, emb_v, lengths, out, o_bs, o_cs, B, H, n_heads, T, window, s)
   if (dk == 96) { VSP_ATTF(96); }
   else if (dk == 64) { VSP_ATTF(64); }
   else if (dk == 32) { VSP_ATTF(32); }
