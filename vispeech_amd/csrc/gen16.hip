@@ -501,12 +501,138 @@ static hipError_t launch_g16_tile(const ClConvArgs& a, int B, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// g16_ups: the kernel-4 transposed convolutions (stride 4: one tap per phase; stride 2: two -- the 64- and 32-channel
+// stages' up-convs, reference models.py:262-268, 282-284) as a STREAMING kernel.  Their GEMM is short (K = KT Cin = 128
+// per output row) and wide in time: an HBM-bound op that the tiled kernel above ran at 12-15 % matrix issue and
+// 1.6-3 TB/s, a block's life being window staging, a few ring steps and an epilogue.  Here
+// time is the M axis of v_mfma_f32_16x16x32_f16: a lane's A fragment is 8 consecutive channels of ONE input row --
+// 32 contiguous bytes of the channels-last activation, read straight from global memory and split in registers; the
+// weights (the packed image above, read as B fragments: same bytes, rows <-> columns) stay in registers for the whole
+// run of a wave; no LDS, no barrier.  A wave owns NMT of the rows' 16-row tiles (ROLES waves share a time range when
+// the weights of all tiles do not fit one wave's registers) and walks TPW 16-row time tiles.
+//   out[phases q + ph - p][co] = bias[co] + sum_tap sum_ci lrelu(x[q - (KT-1) + tap][ci]) w[ph][co][ci][tap]
+static bool g16_ups_on() {
+#ifdef VSP_EXPERIMENTS
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("VSP_G16_UPS"); v = e ? atoi(e) != 0 : 1; }
+  return v != 0;
+#else
+  return true;
+#endif
+}
+template <int KT, int NCH, int NMT, int ROLES>
+__global__ void __launch_bounds__(64 * (ROLES > 4 ? ROLES : 4)) g16_ups(ClConvArgs a, int tiles_per_wave) {
+  constexpr int NWB = ROLES > 4 ? ROLES : 4;            // waves of a block
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kg = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int role = wave % ROLES, stream = wave / ROLES;
+  const int b = blockIdx.y;
+  const int nmt_all = a.phases * a.Cout / 16, mt0 = role * NMT;
+  const int ntiles = (a.Nq + 15) / 16;
+  const int run = blockIdx.x * (NWB / ROLES) + stream;
+  const int tile_lo = run * tiles_per_wave;
+  const int tile_hi = tile_lo + tiles_per_wave < ntiles ? tile_lo + tiles_per_wave : ntiles;
+  if (tile_lo >= ntiles) return;
+
+  // weights: block (chunk, tap, m-tile) of the packed image, hi | lo, this lane's 16 bytes of each
+  f16x8 Bh[KT][NCH][NMT], Bl[KT][NCH][NMT];
+#pragma unroll
+  for (int tap = 0; tap < KT; ++tap)
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int m = 0; m < NMT; ++m) {
+        const size_t blk = (((size_t)c * KT + tap) * nmt_all + mt0 + m) * 2;
+        Bh[tap][c][m] = *reinterpret_cast<const f16x8*>(a.wh + (blk * 64 + lane) * 8);
+        Bl[tap][c][m] = *reinterpret_cast<const f16x8*>(a.wh + ((blk + 1) * 64 + lane) * 8);
+      }
+  float bv[NMT];
+  int co_of[NMT], ph_of[NMT];
+#pragma unroll
+  for (int m = 0; m < NMT; ++m) {
+    const int r = (mt0 + m) * 16 + l15;
+    ph_of[m] = r / a.Cout;
+    co_of[m] = r - ph_of[m] * a.Cout;
+    bv[m] = a.bias ? a.bias[co_of[m]] : 0.f;
+  }
+  const float* xb = a.x + (size_t)b * a.x_bs + kg * 8;
+  float* ob = a.out + (size_t)b * a.o_bs;
+  const float slope = a.in_slope;
+  const bool act = a.in_act != 0;
+
+  // (Measured: requesting the rows of tile + 1 before computing tile costs 32 more registers -- one wave per SIMD instead
+  // of two -- and runs 1.5x slower; splitting the m-tiles over more waves to make room repeats the conversion per wave
+  // and is slower too.  At two waves per SIMD the kernel moves 4.1 GB in 1.0 ms (32-channel stage) / 3.1 GB in 0.95 ms.)
+  for (int tile = tile_lo; tile < tile_hi; ++tile) {
+    const int q0 = tile * 16;
+    // ---- the tile's input rows (one per lane and tap), 8 channels per chunk: two 16-byte loads, all requested first
+    f32x4 raw[KT][NCH][2];
+#pragma unroll
+    for (int tap = 0; tap < KT; ++tap) {
+      const int xr = q0 + l15 - (KT - 1) + tap;
+      const bool ok = xr >= 0 && xr < a.T_in;
+      const float* p = xb + (size_t)(ok ? xr : 0) * a.x_ts;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        raw[tap][c][0] = ok ? *reinterpret_cast<const f32x4*>(p + c * 32) : f32x4{0.f, 0.f, 0.f, 0.f};
+        raw[tap][c][1] = ok ? *reinterpret_cast<const f32x4*>(p + c * 32 + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    f32x4 hh[NMT], cr[NMT];
+#pragma unroll
+    for (int m = 0; m < NMT; ++m) hh[m] = cr[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < KT; ++tap)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        f16x4 h0, l0, h1, l1;
+        g16_split4(raw[tap][c][0], slope, act, h0, l0);
+        g16_split4(raw[tap][c][1], slope, act, h1, l1);
+        const f16x8 ah = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+        const f16x8 al = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) {
+          hh[m] = G16_MFMA(ah, Bh[tap][c][m], hh[m]);
+          cr[m] = G16_MFMA(ah, Bl[tap][c][m], cr[m]);
+          cr[m] = G16_MFMA(al, Bh[tap][c][m], cr[m]);
+        }
+      }
+    // ---- store: lane = output row r (phase, channel), registers = four consecutive times q
+#pragma unroll
+    for (int m = 0; m < NMT; ++m)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int q = q0 + 4 * kg + jj;
+        const int n = a.phases * q + ph_of[m] - a.ups_p;
+        if (q < a.Nq && n >= 0 && n < a.T_store)
+          ob[(size_t)n * a.o_ts + co_of[m]] = hh[m][jj] + cr[m][jj] * (1.f / 2048.f) + bv[m];
+      }
+  }
+}
+
+template <int KT, int NCH, int NMT, int ROLES>
+static hipError_t launch_g16_ups(const ClConvArgs& a, int B, hipStream_t s) {
+  const int ntiles = (a.Nq + 15) / 16;
+  const int tpw = 16;                                   // 256 input rows per wave: the weights (32 KiB) are read once per run
+  constexpr int NWB = ROLES > 4 ? ROLES : 4;
+  const int runs = (ntiles + tpw - 1) / tpw, per_block = NWB / ROLES;
+  hipLaunchKernelGGL((g16_ups<KT, NCH, NMT, ROLES>), dim3((runs + per_block - 1) / per_block, B), dim3(64 * NWB), 0, s, a, tpw);
+  return hipGetLastError();
+}
+
 hipError_t launch_g16_conv(const ClConvArgs& a, int B, hipStream_t s) {
   if ((a.K - 1) * a.dil > G16_HALO || a.K < 1 || a.Nq <= 0 || B <= 0 || a.Cout % 16 || a.Cin % 32 || a.phases < 1 ||
       (a.x_ts & 3) || (a.x_bs & 3) || (reinterpret_cast<uintptr_t>(a.x) & 15) || (a.o_ts & 3) || (a.o_bs & 3) ||
       (reinterpret_cast<uintptr_t>(a.out) & 15))
     return hipErrorInvalidValue;
   const int rows = a.phases * a.Cout;
+  // the short up-convs (kernel 4 at stride 4 or 2): streaming kernel (no residual / accumulate operands there)
+  if (a.terms == 3 && a.phases > 1 && a.dil == 1 && a.pad == a.K - 1 && !a.res && !a.acc_prev && a.div == 1.f &&
+      a.in_slope >= 0.f && a.in_slope <= 1.f && g16_ups_on()) {
+    if (a.K == 2 && a.Cin == 64 && rows == 64) return launch_g16_ups<2, 2, 4, 1>(a, B, s);      // 64 -> 32 channels, stride 2
+    if (a.K == 1 && a.Cin == 128 && rows == 256) return launch_g16_ups<1, 4, 4, 4>(a, B, s);    // 128 -> 64 channels, stride 4
+  }
   // <MW, NW, WM, WN, TERMS>
   if (a.terms == 1) {
     if (rows % 128 == 0) return launch_g16_tile<4, 4, 2, 4, 1>(a, B, s);
