@@ -22,5 +22,9 @@ python3 "$R/bench.py" --workload C2 --batch 1 --steps 50 --warmup 10 --no-cpu-ba
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace" -o t -- python3 "$R/bench.py" --steps 4 --warmup 1 --profile-steps 0 --no-cpu-baseline > "$O/bench_traced.json" 2>> "$O/bench.err" || true
 python3 "$R/tools/trace_fused.py" "$O/trace/t_kernel_trace.csv" > "$O/generator_per_launch.txt" || true
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace_c5" -o t -- python3 "$R/bench.py" --workload C5 --steps 4 --warmup 1 --profile-steps 0 --no-cpu-baseline > "$O/bench_c5_traced.json" 2>> "$O/bench.err" || true
+# one utterance and the 60 s utterance, launch by launch (tools/trace_timeline.py)
+rocprofv3 --kernel-trace --output-format csv -d "$O/trace_one" -o t -- python3 "$R/bench.py" --workload C2 --batch 1 --steps 4 --warmup 2 --profile-steps 0 --no-cpu-baseline > /dev/null 2>> "$O/bench.err" || true
+python3 "$R/tools/trace_timeline.py" "$O/trace_one/t_kernel_trace.csv" > "$O/one_utterance_timeline.txt" || true
+python3 "$R/tools/trace_timeline.py" "$O/trace_c5/t_kernel_trace.csv" > "$O/c5_timeline.txt" || true
 rm -f "$O"/trace*/t_kernel_trace.csv "$O"/pmc_*/p_agent_info.csv
 cat "$O/pytest_gpu.txt"; cut -c1-300 "$O/bench.json"; tail -3 "$O/generator_per_launch.txt"; cat "$O/traffic.json"

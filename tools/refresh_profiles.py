@@ -19,6 +19,9 @@ if os.path.exists(os.path.join(F, "trace_c5", "t_kernel_stats.csv")):
     shutil.copy(os.path.join(F, "trace_c5", "t_kernel_stats.csv"), os.path.join(P, f"{tag}_c5_kernel_stats.csv"))
 shutil.copy(os.path.join(F, "generator_per_launch.txt"), os.path.join(P, f"{tag}_generator_per_launch.txt"))
 shutil.copy(os.path.join(F, "pytest_gpu.txt"), os.path.join(P, f"{tag}_pytest_gpu.txt"))
+for f in ("one_utterance_timeline.txt", "c5_timeline.txt"):
+    if os.path.exists(os.path.join(F, f)):
+        shutil.copy(os.path.join(F, f), os.path.join(P, f"{tag}_{f}"))
 shutil.copy(os.path.join(F, "traffic.json"), os.path.join(P, "traffic.json"))
 out = {}
 for f, k in (("bench_c2", "C2"), ("bench_c5", "C5"), ("bench_controls_duration", "C3_duration_supplied_F0_energy_predicted"),
