@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 namespace vsp {
 
@@ -124,7 +125,7 @@ constexpr int CONV_OOR = 0x7ffffff0;
 
 template <int MT, int NT>
 __device__ __forceinline__ void conv_epi_load(const ConvArgs& a, ConvEpi<MT, NT>& e, int mtile0, int n_mtiles, int t0, int wn,
-                                              int l31, int h, int b) {
+                                              int l31, int h, int b, int what = 3) {   // what: 1 = rows, 2 = tiles
   const float* resb = a.res ? a.res + (size_t)b * a.r_bs : nullptr;
   float* outb = a.out + (size_t)b * a.o_bs;
   const float* condb = a.cond ? a.cond + (size_t)b * a.cond_bs : nullptr;
@@ -148,11 +149,14 @@ __device__ __forceinline__ void conv_epi_load(const ConvArgs& a, ConvEpi<MT, NT>
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int mtile = mtile0 + mt;
+    if (what & 1) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      row_vec(a.bias, mtile * 32 + 8 * g + 4 * h, &e.bv[mt][4 * g]);
-      row_vec(condb, mtile * 32 + 8 * g + 4 * h, &e.cv[mt][4 * g]);
+      for (int g = 0; g < 4; ++g) {
+        row_vec(a.bias, mtile * 32 + 8 * g + 4 * h, &e.bv[mt][4 * g]);
+        row_vec(condb, mtile * 32 + 8 * g + 4 * h, &e.cv[mt][4 * g]);
+      }
     }
+    if (!(what & 2)) continue;
     const bool second = a.split_row && mtile * 32 >= a.split_row;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -1155,6 +1159,262 @@ static hipError_t launch_tile(const ConvArgs& a, int B, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// conv_frame_splitk: the form for grids of a FEW DOZEN blocks (one utterance).  There even the kernel above is a chain:
+// its four waves walk all K Cin / 32 steps of the tile together (stamps: 41 us for the 30 steps of a k5 WN layer, of
+// which 23 us are the steps).  Here the four waves of a block split the INPUT CHANNELS: wave w takes chunks w, w + 4, ...
+// of a 64 x 64 tile, with its own window slots, its own weights and no barrier at all until the four partial tiles meet
+// in LDS; wave w then finishes tile (w / 2, w % 2) -- the sum of the four partials in the accumulator layout -- with the
+// shared epilogue (the gate: waves 0 and 1 take both row tiles of a column tile).
+//   * weights: straight from the packed image into registers (a lane's 16 bytes of each fragment), two taps at a time,
+//     two register sets: the next group is requested before the current one is multiplied;
+//   * window: plain 16-byte loads into registers (all lanes busy: a lane takes (pair row, four times) positions of the
+//     chunk's 16 x LW4 grid), converted and written to the wave's LDS slot of the chunk's parity; the next chunk's loads
+//     are requested as soon as the registers are free;
+//   * every load is unconditional (addresses clamped), so the compiler's counted waits see the same number of
+//     operations on every path and leave the prefetches in flight.
+// The sum over chunks is taken in a different order than in the kernels above (four partial sums): fp32 rounding only.
+template <int K, bool GATE>
+__global__ void __launch_bounds__(256, 1) conv_frame_splitk(ConvArgs a) {
+  constexpr int MT = 2, NT = 1, NWV = 4;
+  constexpr int HALO = K == 1 ? 0 : FR_HALO;
+  constexpr int BN = 32 * NT, LWP = BN + HALO, LWP4 = LWP / 4;
+  constexpr int WBUF = CONV_CK * LWP * 4;                       // bytes of a window slot (hi image | lo image)
+  constexpr int NIT = (16 * LWP4 + 63) / 64;                    // staging sweeps of a wave over the (pair row, four times) grid
+  constexpr int GT = 2;                                         // taps per weight group
+  constexpr int GPC = (K + GT - 1) / GT;                        // groups per chunk
+  static_assert(2 * NWV * WBUF >= NWV * MT * NT * 16 * 64 * 4 || true, "");
+  extern __shared__ __attribute__((aligned(16))) float xs[];
+  char* const wbase = reinterpret_cast<char*>(xs);
+  constexpr int PART = NWV * MT * NT * 16 * 64 * 4;             // bytes of the four partial tiles
+  constexpr int LDSB = 2 * NWV * WBUF > PART ? 2 * NWV * WBUF : PART;
+  (void)LDSB;
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int b = blockIdx.z;
+  const int t0 = blockIdx.x * BN;
+  const int mtile0 = blockIdx.y * MT;
+  const int n_mtiles = (a.M + 31) >> 5;
+  const int nch = a.nchunks;
+  const int total_it = nch * K;
+  // ---- the bias / conditioning rows of the tile this wave will finish (the gate: wave 0 both row tiles; else waves
+  // 0 and 1 one each), first; its residual / destination values are requested when the main loop is done
+  constexpr int FM = GATE ? 2 : 1;
+  ConvEpi<FM, 1> epi;
+  const bool finisher = wave < (GATE ? 1 : 2);
+  const int fmt0 = mtile0 + (GATE ? 0 : wave);
+  if (finisher) conv_epi_load<FM, 1>(a, epi, fmt0, n_mtiles, t0, 0, l31, h, b, 1);
+
+  // ---- weights of a group (chunk c, taps [tap0, tap0 + GT)): a lane's 16 bytes of [mt][ks][hi | lo]
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  struct WSet { f32x4v w[GT][MT][4]; };
+  const f32x4v* wp4 = reinterpret_cast<const f32x4v*>(a.wp);
+  int mt_c[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) mt_c[mt] = mtile0 + mt < n_mtiles ? mtile0 + mt : n_mtiles - 1;
+  auto wload = [&](WSet& W, int c, int g) {
+    c = c < nch ? c : nch - 1;                                  // (past the end: a harmless re-read)
+#pragma unroll
+    for (int u = 0; u < GT; ++u) {
+      int tap = g * GT + u;
+      tap = tap < K ? tap : K - 1;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          W.w[u][mt][q] = wp4[(((size_t)mt_c[mt] * total_it + c * K + tap) * 4 + q) * 64 + lane];
+    }
+  };
+  // ---- window of a chunk: positions idx = sweep 64 + lane of the 16 x LW4 grid (pair row p, four times c4)
+  const float* xb = a.x + (size_t)b * a.x_bs;
+  const int LW = BN + (K - 1) * a.dil;
+  const int t_start = ((t0 - a.pad) >> 2) << 2;
+  const int off = (t0 - a.pad) - t_start;
+  const int LW4 = (LW + off + 3) >> 2;
+  const int len = a.lengths ? (int)a.lengths[b] : 0x7fffffff;
+  const int lim = a.in_mask ? (len < a.T_in ? len : a.T_in) : a.T_in;
+  const float slope_eff = a.in_act ? a.in_slope : 1.f;
+  int xp[NIT], xt[NIT];                 // pair row, first time of this lane's position per sweep (pair row 16 = none)
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int idx = it * 64 + lane;
+    const int p = idx / LW4, c4 = idx - p * LW4;
+    xp[it] = p < 16 ? p : 16;
+    xt[it] = t_start + 4 * c4;
+  }
+  struct XSet { f32x4v va[NIT], vb[NIT]; };
+  auto xload = [&](XSet& X, int c) {
+    c = c < nch ? c : nch - 1;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int ci = c * CONV_CK + 2 * xp[it];
+      const bool tin = xp[it] < 16 && xt[it] >= 0 && xt[it] < a.T_in;
+      const float* pa = xb + (size_t)(tin && ci < a.Cin ? ci : 0) * a.x_cs + (tin ? xt[it] : 0);
+      const float* pb = xb + (size_t)(tin && ci + 1 < a.Cin ? ci + 1 : 0) * a.x_cs + (tin ? xt[it] : 0);
+      X.va[it] = *reinterpret_cast<const f32x4v*>(pa);
+      X.vb[it] = *reinterpret_cast<const f32x4v*>(pb);
+    }
+  };
+  typedef float f32x2v __attribute__((ext_vector_type(2)));
+  auto xconvert = [&](const XSet& X, int c, int slot) {
+    unsigned* const ph = reinterpret_cast<unsigned*>(wbase + (wave * 2 + slot) * WBUF);
+    unsigned* const pl = ph + (CONV_CK / 2) * LWP;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      if (xp[it] >= 16) continue;
+      const int ci = c * CONV_CK + 2 * xp[it];
+      const bool tin = xt[it] >= 0 && xt[it] < a.T_in;
+      const bool ina = tin && ci < a.Cin, inb = tin && ci + 1 < a.Cin;
+      unsigned wh4[4], wl4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        f32x2v x = {X.va[it][u], X.vb[it][u]};
+        x.x = (ina && xt[it] + u < lim) ? x.x : 0.f;
+        x.y = (inb && xt[it] + u < lim) ? x.y : 0.f;
+        const f32x2v y = x * slope_eff;
+        asm("v_max_f32 %0, %1, %2" : "=v"(x.x) : "v"(x.x), "v"(y.x));
+        asm("v_max_f32 %0, %1, %2" : "=v"(x.y) : "v"(x.y), "v"(y.y));
+        const f32x2v hf = {__uint_as_float(__float_as_uint(x.x) & 0xffffe000u), __uint_as_float(__float_as_uint(x.y) & 0xffffe000u)};
+        const f32x2v lf = (x - hf) * 2048.f;
+        wh4[u] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(hf.x, hf.y));
+        wl4[u] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lf.x, lf.y));
+      }
+      const int o = xp[it] * LWP + (xt[it] - t_start);
+      *reinterpret_cast<u32x4*>(ph + o) = u32x4{wh4[0], wh4[1], wh4[2], wh4[3]};
+      *reinterpret_cast<u32x4*>(pl + o) = u32x4{wl4[0], wl4[1], wl4[2], wl4[3]};
+    }
+  };
+
+  f32x16 acc[MT][NT], crs[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = crs[mt][nt][r] = 0.f;
+  // MFMAs of a group from the wave's window slot
+  auto compute = [&](const WSet& W, int g, int slot) {
+    const unsigned* const ph = reinterpret_cast<const unsigned*>(wbase + (wave * 2 + slot) * WBUF);
+    const unsigned* const pl = ph + (CONV_CK / 2) * LWP;
+#pragma unroll
+    for (int u = 0; u < GT; ++u) {
+      if (g * GT + u >= K) break;
+      const int col = l31 + off + (g * GT + u) * a.dil;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        f16x8 bh[NT], bl[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const unsigned* p = ph + (8 * ks + 4 * h) * LWP + col + nt * 32;
+          const unsigned* q = pl + (8 * ks + 4 * h) * LWP + col + nt * 32;
+          bh[nt] = __builtin_bit_cast(f16x8, u32x4{p[0], p[LWP], p[2 * LWP], p[3 * LWP]});
+          bl[nt] = __builtin_bit_cast(f16x8, u32x4{q[0], q[LWP], q[2 * LWP], q[3 * LWP]});
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const f16x8 ah = __builtin_bit_cast(f16x8, W.w[u][mt][2 * ks]);
+          const f16x8 al = __builtin_bit_cast(f16x8, W.w[u][mt][2 * ks + 1]);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = FR_MFMA16(ah, bh[nt], acc[mt][nt]);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) crs[mt][nt] = FR_MFMA16(ah, bl[nt], crs[mt][nt]);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) crs[mt][nt] = FR_MFMA16(al, bh[nt], crs[mt][nt]);
+        }
+      }
+    }
+  };
+
+  // ---- this wave's chunks: c_j = wave + 4 j
+  const int nj = nch > wave ? (nch - wave + NWV - 1) / NWV : 0;
+  WSet WA, WB;
+  XSet XR;
+  if (nj > 0) {
+    xload(XR, wave);
+    wload(WA, wave, 0);
+    xconvert(XR, wave, 0);
+    xload(XR, wave + NWV);                      // (the second chunk's window, or a harmless re-read)
+    // two chunks per iteration: the group sequence (and with it the set each group uses) is static
+    for (int j = 0; j < nj; j += 2) {
+      const int c0 = wave + NWV * j, c1 = c0 + NWV;
+      const bool has1 = j + 1 < nj;
+      // chunk c0 from slot 0: groups alternate WA, WB, starting with WA when GPC is even or this is the first chunk
+      // of the pair (2 GPC groups per iteration keep the alternation aligned)
+      auto chunk_groups = [&](int c, int cnext, int slot, auto FIRST_IS_A) {
+        constexpr bool first_a = decltype(FIRST_IS_A)::value;
+#pragma unroll
+        for (int g = 0; g < GPC; ++g) {
+          const bool use_a = first_a ? (g % 2 == 0) : (g % 2 == 1);
+          // request the next group (of this chunk, or the first of the next) into the other set
+          if (g + 1 < GPC) { if (use_a) wload(WB, c, g + 1); else wload(WA, c, g + 1); }
+          else { if (use_a) wload(WB, cnext, 0); else wload(WA, cnext, 0); }
+          if (use_a) compute(WA, g, slot); else compute(WB, g, slot);
+        }
+      };
+      chunk_groups(c0, c1, 0, std::true_type{});
+      if (has1) xconvert(XR, c1, 1);            // (its loads went out a chunk ago)
+      xload(XR, c1 + NWV);
+      if (has1) {
+        if constexpr (GPC % 2 == 0) chunk_groups(c1, c1 + NWV, 1, std::true_type{});
+        else chunk_groups(c1, c1 + NWV, 1, std::false_type{});
+        if (j + 2 < nj) xconvert(XR, c1 + NWV, 0);
+        xload(XR, c1 + 2 * NWV);
+      }
+    }
+  }
+  if (finisher) conv_epi_load<FM, 1>(a, epi, fmt0, n_mtiles, t0, 0, l31, h, b, 2);
+  // ---- the four partial tiles meet: [wave][tile][register][lane] floats over the window slots
+  __syncthreads();
+  float* const part = reinterpret_cast<float*>(wbase);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        part[(((wave * MT + mt) * NT + nt) * 16 + r) * 64 + lane] = acc[mt][nt][r] + crs[mt][nt][r] * (1.f / 2048.f);
+  __syncthreads();
+  auto gather = [&](int mt, int nt, f32x16& v) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float sum = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < NWV; ++w2) sum += part[(((w2 * MT + mt) * NT + nt) * 16 + r) * 64 + lane];
+      v[r] = sum;
+    }
+  };
+  if (finisher) {
+    f32x16 tf[FM][1];
+    if constexpr (GATE) { gather(0, 0, tf[0][0]); gather(1, 0, tf[1][0]); }
+    else gather(wave, 0, tf[0][0]);
+    conv_epi_store<FM, 1>(a, tf, epi, fmt0, n_mtiles, t0, 0, l31, h, b, len);
+  }
+}
+
+template <int K, bool GATE>
+static hipError_t launch_splitk_g(const ConvArgs& a, int B, hipStream_t s) {
+  constexpr int LWP = 32 + (K == 1 ? 0 : FR_HALO);
+  constexpr size_t win = (size_t)2 * 4 * CONV_CK * LWP * 4, part = (size_t)4 * 2 * 16 * 64 * 4;
+  constexpr size_t lds = win > part ? win : part;
+  static bool attr_set = false;
+  auto kern = conv_frame_splitk<K, GATE>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  dim3 grid((a.Nq + 31) / 32, (a.M + 63) / 64, B);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  return hipGetLastError();
+}
+template <int K>
+static hipError_t launch_splitk(const ConvArgs& a, int B, hipStream_t s) {
+  return a.act == 2 ? launch_splitk_g<K, true>(a, B, s) : launch_splitk_g<K, false>(a, B, s);
+}
+
 // Grids up to this many 64 x 128 tiles (two rounds of the chip at one block per CU) take the latency kernel; above it the
 // throughput kernel's three co-resident blocks per CU hide a block's serial steps better (C3, same box: 84.8 ms against
 // 88.8 with the latency kernel everywhere; one utterance 5.22 against 5.34 without it, the 5168-frame utterance 18.8
@@ -1163,6 +1423,18 @@ static long fr_max_blocks() {
 #ifdef VSP_EXPERIMENTS
   static long v = -1;
   if (v < 0) { const char* e = getenv("VSP_FR_BLOCKS"); v = e ? atol(e) : 512; }
+  return v;
+#else
+  return 512;
+#endif
+}
+
+// Grids up to this many 64 x 32 tiles take the channel-split kernel (same box: one utterance 5.17 -> 3.9 ms, the
+// 5168-frame utterance 18.4 -> 17.8, C2 24.5 -> 24.1; thresholds 128 / 256 / 512 / 1024 / 4096 swept).
+static long fr_splitk_blocks() {
+#ifdef VSP_EXPERIMENTS
+  static long v = -1;
+  if (v < 0) { const char* e = getenv("VSP_FR_SPLITK"); v = e ? atol(e) : 512; }
   return v;
 #else
   return 512;
@@ -1189,6 +1461,14 @@ hipError_t launch_conv(const ConvArgs& a, int B, hipStream_t s) {
     if (vec && (a.K - 1) * a.dil + 6 <= FR_HALO && (a.K > 1 || a.pad == 0) && sl >= 0.f && sl <= 1.f && (a.M > 32 || gate)) {
       const long blocks = (long)B * ((a.Nq + 127) / 128) * ((a.M + 63) / 64);
       hipError_t e = hipSuccess;
+      // a few dozen blocks: the channel-split form
+      const long blocks64 = (long)B * ((a.Nq + 31) / 32) * ((a.M + 63) / 64);
+      // (short time axes -- the phoneme-rate encoder of a whole batch -- have nothing better up to a few rounds of blocks)
+      if (blocks64 <= (a.Nq <= 96 ? 8 : 1) * fr_splitk_blocks() && a.nchunks >= 2) {
+        if (a.K == 1) return launch_splitk<1>(a, B, s);
+        if (a.K == 3) return launch_splitk<3>(a, B, s);
+        if (a.K == 5) return launch_splitk<5>(a, B, s);
+      }
       if (a.Nq <= 96) { if (blocks * 2 <= fr_max_blocks() && launch_frame_k<2, 1, 1, 2>(a, B, s, e)) return e; }
       else if (blocks <= fr_max_blocks()) { if (launch_frame_k<2, 1, 1, 4>(a, B, s, e)) return e; }
     }
