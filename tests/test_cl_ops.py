@@ -129,11 +129,13 @@ def test_cl_ops_refuse_what_they_cannot_do(lib):
 @pytest.mark.parametrize("cin,cout,k,dil,act", [(192, 192, 1, 1, 0), (192, 384, 5, 1, 2), (1, 192, 3, 1, 0), (192, 1, 1, 1, 0),
                                                 (192, 2, 3, 1, 0), (80, 192, 5, 1, 1), (768, 192, 3, 1, 0), (192, 768, 3, 1, 1),
                                                 (96, 192, 1, 1, 0), (192, 128, 7, 2, 0), (33, 65, 3, 1, 1), (192, 384, 3, 3, 2)])
-@pytest.mark.parametrize("b,t", [(1, 4), (3, 60), (2, 128), (2, 132), (1, 488), (1, 1100)])
+@pytest.mark.parametrize("b,t", [(1, 4), (3, 60), (2, 128), (2, 132), (1, 488), (1, 1100), (2, 2600)])
 def test_conv1d_matches_torch(lib, cin, cout, k, dil, act, b, t):
-    """The frame-rate convolution kernel (conv1d_f32_mfma: split-f16 with the LDS-DMA weight ring, and the f32 MFMA
-    form) with its fused prologue / epilogue on ragged channel and row counts, one-row outputs, the WN gate, input and
-    output masks, residual.  Reference semantics: masked Conv1d of attentions.py:277-285 / modules.py:148-176."""
+    """The frame-rate convolution kernels with their fused prologue / epilogue on ragged channel and row counts, one-row
+    outputs, the WN gate, input and output masks, residual: by grid size the channel-split kernel (conv_frame_splitk:
+    every size here up to 1100 columns), the one-barrier-per-K-taps kernel (conv_frame_f16s: 2 x 2600 columns) or the
+    throughput kernel (conv1d_f32_mfma with the LDS-DMA weight ring: tap counts other than 1 / 3 / 5, one-row outputs),
+    and the f32 MFMA form.  Reference semantics: masked Conv1d of attentions.py:277-285 / modules.py:148-176."""
     r = np.random.Generator(np.random.PCG64(cin * 7 + cout * 3 + k + t))
     x = r.standard_normal((b, cin, t)).astype(np.float32)
     w = (r.standard_normal((cout, cin, k)) / np.sqrt(cin * k)).astype(np.float32)
