@@ -178,25 +178,37 @@ class Engine:
         _lib.check(rc, self.ctx, "vsp_frame_lengths_host")
         return list(host), int(mx.value)
 
-    def decode(self, enc: Mapping[str, torch.Tensor], Tf: int, noise: Optional[torch.Tensor], noise_scale: float,
-               max_len: Optional[int] = None, noise_seed: int = 0) -> Dict[str, torch.Tensor]:
-        """``noise`` None with ``noise_scale`` != 0: the library draws it on the device (``vsp_randn(noise_seed)``)."""
+    def decode_buffers(self, B: int, Tp: int, Tf: int, max_len: Optional[int] = None):
+        """Output tensors and workspace of ``decode`` for a padded frame count ``Tf``.  A caller that knows ``Tf`` before
+        the frame counts are read back (a sharded batch's global padding, ``t_f``) allocates them while the GPU is still
+        busy with ``encode``: the host work between the two halves is then the read itself."""
         d = self.dims
-        B, _, Tp = enc["x_var"].shape
         inter = d.inter_channels
         if max_len is not None and int(max_len) < 0:
             raise ValueError("max_len must be >= 0 (None = no truncation)")   # the C side reads < 0 as "no limit"
         Tdec = Tf if max_len is None else min(Tf, int(max_len))
-        if noise is not None:
-            noise = _dev_f32(noise, self.device)
-            if tuple(noise.shape) != (B, inter, Tf):
-                raise ValueError(f"noise must be [{B},{inter},{Tf}], got {tuple(noise.shape)}")
         o_buf = self._f(B, 1, max(Tdec * d.total_upsample, 1))      # (never a null pointer: max_len = 0 skips the vocoder)
         out = dict(o=o_buf[:, :, :Tdec * d.total_upsample] if Tdec * d.total_upsample != o_buf.shape[2] else o_buf,
                    x_mask=torch.empty(B, 1, Tf, dtype=torch.uint8, device=self.device),
                    z=self._f(B, inter, Tf), z_p=self._f(B, inter, Tf), m_p=self._f(B, inter, Tf),
                    logs_p=self._f(B, inter, Tf))
         ws = self._workspace("decode", self.lib.vsp_decode_workspace_bytes(self.ctx, B, Tp, Tf))
+        return dict(Tf=int(Tf), Tdec=Tdec, o_buf=o_buf, out=out, ws=ws, max_len=max_len)
+
+    def decode(self, enc: Mapping[str, torch.Tensor], Tf: int, noise: Optional[torch.Tensor], noise_scale: float,
+               max_len: Optional[int] = None, noise_seed: int = 0, bufs=None) -> Dict[str, torch.Tensor]:
+        """``noise`` None with ``noise_scale`` != 0: the library draws it on the device (``vsp_randn(noise_seed)``).
+        ``bufs``: a ``decode_buffers`` result for the same ``Tf`` / ``max_len`` (else allocated here)."""
+        d = self.dims
+        B, _, Tp = enc["x_var"].shape
+        inter = d.inter_channels
+        if bufs is None or bufs["Tf"] != int(Tf) or bufs["max_len"] != max_len:
+            bufs = self.decode_buffers(B, Tp, Tf, max_len)
+        Tdec, o_buf, out, ws = bufs["Tdec"], bufs["o_buf"], bufs["out"], bufs["ws"]
+        if noise is not None:
+            noise = _dev_f32(noise, self.device)
+            if tuple(noise.shape) != (B, inter, Tf):
+                raise ValueError(f"noise must be [{B},{inter},{Tf}], got {tuple(noise.shape)}")
         with torch.cuda.device(self.device):
             rc = self.lib.vsp_decode(self.ctx, self._stream(), B, Tp, Tf, -1 if max_len is None else Tdec,
                                      _ptr(enc["x_var"]), _ptr(enc["g"]), _ptr(enc["cum_dur"]),

@@ -141,6 +141,8 @@ class SynthesizerTrn:
         p_t, p_s = split(pitch_control)
         e_t, e_s = split(energy_control)
         enc = eng.encode(phonemes, phonemes_lengths, sid, d_t, p_t, e_t, d_s, p_s, e_s)
+        # (a known padding: the second half's tensors are allocated while the GPU is still busy with the first)
+        bufs = eng.decode_buffers(B, Tp, int(t_f), max_len) if t_f is not None and int(t_f) > 0 else None
         _, tf_local = eng.frame_lengths_host(enc["frame_lengths"])
         Tf = tf_local if t_f is None else max(int(t_f), tf_local)
         if Tf <= 0:
@@ -148,7 +150,7 @@ class SynthesizerTrn:
         ns = float(noise_scale)
         if noise is None and ns != 0.0 and noise_seed is None:
             noise = torch.randn(B, self.dims.inter_channels, Tf, dtype=torch.float32, device=eng.device)
-        dec = eng.decode(enc, Tf, noise, ns, max_len, noise_seed=0 if noise_seed is None else int(noise_seed))
+        dec = eng.decode(enc, Tf, noise, ns, max_len, noise_seed=0 if noise_seed is None else int(noise_seed), bufs=bufs)
         duration = duration_control if d_t is not None else enc["duration"].view(B, 1, Tp)
         return (dec["o"], dec["x_mask"], (dec["z"], dec["z_p"], dec["m_p"], dec["logs_p"]), duration, enc["F0"],
                 enc["energy"])
