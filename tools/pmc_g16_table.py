@@ -7,7 +7,7 @@ import csv
 import re
 import sys
 
-FAM = re.compile(r"(g16_conv|g16_pair|g16_chain|g16_ups|conv1d_f32_mfma|conv_frame_f16s|attn_relpos_f16s)<([^>]*)>")
+FAM = re.compile(r"(g16_conv|g16_pair|g16_chain|g16_ups|conv1d_f32_mfma|conv_frame_f16s|conv_frame_splitk|attn_relpos_f16s)<([^>]*)>")
 tot = collections.OrderedDict()   # family -> counter -> sum
 cnt = collections.Counter()
 for path in sys.argv[1:]:
