@@ -1131,12 +1131,11 @@ static hipError_t launch_frame(const ConvArgs& a, int B, hipStream_t s) {
 // the latency form for a tile shape, by tap count (other tap counts: the throughput kernel)
 template <int MT, int NT, int WM, int WN>
 static bool launch_frame_k(const ConvArgs& a, int B, hipStream_t s, hipError_t& e) {
-  constexpr int NW = WM * WN;
   switch (a.K) {
     case 1: e = launch_frame<MT, NT, WM, WN, 1, 2, 3, 3>(a, B, s); return true;
     case 3: e = launch_frame<MT, NT, WM, WN, 3, 1, 3, 3>(a, B, s); return true;
     case 5: e = launch_frame<MT, NT, WM, WN, 5, 1, 2, 3>(a, B, s); return true;
-    default: (void)NW; return false;
+    default: return false;
   }
 }
 
@@ -1183,12 +1182,9 @@ __global__ void __launch_bounds__(256, 1) conv_frame_splitk(ConvArgs a) {
   constexpr int NIT = (16 * LWP4 + 63) / 64;                    // staging sweeps of a wave over the (pair row, four times) grid
   constexpr int GT = 2;                                         // taps per weight group
   constexpr int GPC = (K + GT - 1) / GT;                        // groups per chunk
-  static_assert(2 * NWV * WBUF >= NWV * MT * NT * 16 * 64 * 4 || true, "");
   extern __shared__ __attribute__((aligned(16))) float xs[];
   char* const wbase = reinterpret_cast<char*>(xs);
-  constexpr int PART = NWV * MT * NT * 16 * 64 * 4;             // bytes of the four partial tiles
-  constexpr int LDSB = 2 * NWV * WBUF > PART ? 2 * NWV * WBUF : PART;
-  (void)LDSB;
+  // (dynamic LDS = max(window slots 2 NWV WBUF, the four partial tiles NWV MT NT 16 64 4 bytes): launch_splitk_g)
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
