@@ -78,21 +78,21 @@ size_t attn_pack_bytes(int B, int n_heads, int DK, int T) {
 //                        Vp:     [b][head][group32][dtile16][hi|lo][lane][8]  (lane = d % 16 + 16 * q4, element j =
 //                                key 32 g + (j < 4 ? 4 q4 + j : 16 + 4 q4 + j - 4): the order in which a lane of two
 //                                16-key S^T accumulator tiles holds its keys)
-// One block = 64 time steps of one (b, head); values beyond T are zero.
+// One block = 64 time steps of one (b, head) of q, k or v; values beyond T are zero.
 template <int DK>
 __global__ void __launch_bounds__(256) attn_pack_f16s(const float* __restrict__ qkv, long bs, long cs, int H, int T,
                                                        _Float16* __restrict__ Qp, _Float16* __restrict__ Kp,
                                                        _Float16* __restrict__ Vp) {
   constexpr int NC = DK / 32, ND = DK / 16;
   __shared__ float tile[DK][65];
-  const int b = blockIdx.z, hd = blockIdx.y, t0 = blockIdx.x * 64, tid = threadIdx.x;
+  const int b = blockIdx.z / 3, hd = blockIdx.y, t0 = blockIdx.x * 64, tid = threadIdx.x;
   const int n_heads = gridDim.y;
   const size_t tpad = (size_t)gridDim.x * 64;
   const size_t img = ((size_t)b * n_heads + hd) * tpad * DK * 2;     // halfs per image (hi + lo)
   const float qscale = AF_QS * AF_LOG2E / sqrtf((float)DK);
-  for (int which = 0; which < 3; ++which) {
+  {
+    const int which = blockIdx.z % 3;            // q, k or v: one block each (a launch of a few dozen blocks is latency)
     const float* src = qkv + (size_t)b * bs + (size_t)(which * H + hd * DK) * cs;
-    __syncthreads();
     for (int idx = tid; idx < DK * 64; idx += 256) {
       const int d = idx >> 6, tl = idx & 63;
       tile[d][tl] = t0 + tl < T ? src[(size_t)d * cs + t0 + tl] : 0.f;
@@ -449,7 +449,7 @@ hipError_t launch_attention_f16s(const float* qkv, long qkv_bs, long qkv_cs, con
   _Float16* Qp = static_cast<_Float16*>(workspace);
   _Float16* Kp = reinterpret_cast<_Float16*>(static_cast<char*>(workspace) + one);
   _Float16* Vp = reinterpret_cast<_Float16*>(static_cast<char*>(workspace) + 2 * one);
-  const dim3 pgrid((T + 63) / 64, n_heads, B);
+  const dim3 pgrid((T + 63) / 64, n_heads, 3 * B);
   // 128-query blocks when they fill the chip; 64-query blocks (one query tile per wave) otherwise
   const bool small = (long)((T + 127) / 128) * n_heads * B < 512;
 #define VSP_ATTF(DKV)                                                                                                   \
