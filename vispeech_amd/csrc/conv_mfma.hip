@@ -1411,6 +1411,38 @@ static hipError_t launch_splitk(const ConvArgs& a, int B, hipStream_t s) {
   return a.act == 2 ? launch_splitk_g<K, true>(a, B, s) : launch_splitk_g<K, false>(a, B, s);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// conv_t1_gemv: a 1x1 convolution on ONE time step -- the cond_layer(g) / cond(g) projections of the speaker embedding
+// (reference modules.py:153-155, models.py:279, 507): out[b][m] = bias[m] + sum_ci w[m][ci] x[b][ci].  A GEMV: one
+// thread per output row reads its 16-byte pieces of the packed split-f16 image (hi + lo 2^-11 = the fp32 weight to 22
+// bits, exactly what the MFMA path multiplies) and accumulates in fp32 against the full-precision input.  The matrix
+// kernels spent 38 us on these (a 64-row tile per block for a single column); this is one memory round trip.
+__global__ void __launch_bounds__(256) conv_t1_gemv(ConvArgs a) {
+  __shared__ float xv[2048];
+  const int tid = threadIdx.x, b = blockIdx.y, m = blockIdx.x * 256 + tid;
+  for (int i = tid; i < a.Cin; i += 256) xv[i] = a.x[(size_t)b * a.x_bs + (size_t)i * a.x_cs];
+  __syncthreads();
+  if (m >= a.M) return;
+  const int mtile = m >> 5, rin = m & 31;
+  float acc = a.bias ? a.bias[m] : 0.f;
+  const uint4* wp = reinterpret_cast<const uint4*>(a.wp);
+  for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+    const size_t blk = ((size_t)mtile * a.nchunks + chunk) * 4;         // 1 KiB sub-images [ks][hi | lo] of the 4 KiB block
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const uint4 qh = wp[(blk + ks * 2) * 64 + rin + 32 * hh], ql = wp[(blk + ks * 2 + 1) * 64 + rin + 32 * hh];
+        const f16x8 wh = __builtin_bit_cast(f16x8, qh), wl = __builtin_bit_cast(f16x8, ql);
+        const int ci0 = chunk * CONV_CK + ks * 16 + hh * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (ci0 + j < a.Cin) acc = fmaf((float)wh[j] + (float)wl[j] * (1.f / 2048.f), xv[ci0 + j], acc);
+      }
+  }
+  a.out[(size_t)b * a.o_bs + (size_t)m * a.o_cs] = acc;
+}
+
 // Grids up to this many 64 x 128 tiles (two rounds of the chip at one block per CU) take the latency kernel; above it the
 // throughput kernel's three co-resident blocks per CU hide a block's serial steps better (C3, same box: 84.8 ms against
 // 88.8 with the latency kernel everywhere; one utterance 5.22 against 5.34 without it, the 5168-frame utterance 18.8
@@ -1451,6 +1483,12 @@ hipError_t launch_conv(const ConvArgs& a, int B, hipStream_t s) {
 #endif
   if (ring && a.f16s) {
     if (a.ups_s > 0) return hipErrorInvalidValue;
+    // one time step, plain epilogue: the cond(g) projections
+    if (a.K == 1 && a.T_in == 1 && a.Nq == 1 && a.Cin <= 2048 && a.act == 0 && !a.res && !a.cond && !a.in_mask && !a.in_act &&
+        !a.mask_pre && !a.mask_post && !a.acc_prev && !a.split_row && a.alpha == 1.f && a.div == 1.f) {
+      hipLaunchKernelGGL(conv_t1_gemv, dim3((a.M + 255) / 256, B), dim3(256), 0, s, a);
+      return hipGetLastError();
+    }
     // the latency form (conv_frame_f16s) where the grid does not fill the chip: 64-row tiles, at most two rounds of blocks
     const bool vec = ((a.x_cs & 3) == 0) && ((a.x_bs & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
     const float sl = a.in_act ? a.in_slope : 1.f;
@@ -1464,6 +1502,8 @@ hipError_t launch_conv(const ConvArgs& a, int B, hipStream_t s) {
         if (a.K == 1) return launch_splitk<1>(a, B, s);
         if (a.K == 3) return launch_splitk<3>(a, B, s);
         if (a.K == 5) return launch_splitk<5>(a, B, s);
+        // (k7 = the generator's conv_pre stays on ONE kernel at every size: the streamed vocoder and the locality
+        // tests compare generator outputs of different lengths bit for bit)
       }
       if (a.Nq <= 96) { if (blocks * 2 <= fr_max_blocks() && launch_frame_k<2, 1, 1, 2>(a, B, s, e)) return e; }
       else if (blocks <= fr_max_blocks()) { if (launch_frame_k<2, 1, 1, 4>(a, B, s, e)) return e; }
