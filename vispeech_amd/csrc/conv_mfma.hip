@@ -1425,7 +1425,8 @@ __global__ void __launch_bounds__(256) conv_t1_gemv(ConvArgs a) {
   if (m >= a.M) return;
   const int mtile = m >> 5, rin = m & 31;
   float acc = a.bias ? a.bias[m] : 0.f;
-  const uint4* wp = reinterpret_cast<const uint4*>(a.wp);
+  const uint4* __restrict__ wp = reinterpret_cast<const uint4*>(a.wp);
+#pragma unroll 4                      // (four chunks' loads in flight: the loop is one memory round trip per pass otherwise)
   for (int chunk = 0; chunk < a.nchunks; ++chunk) {
     const size_t blk = ((size_t)mtile * a.nchunks + chunk) * 4;         // 1 KiB sub-images [ks][hi | lo] of the 4 KiB block
 #pragma unroll
@@ -1443,17 +1444,17 @@ __global__ void __launch_bounds__(256) conv_t1_gemv(ConvArgs a) {
   a.out[(size_t)b * a.o_bs + (size_t)m * a.o_cs] = acc;
 }
 
-// Grids up to this many 64 x 128 tiles (two rounds of the chip at one block per CU) take the latency kernel; above it the
-// throughput kernel's three co-resident blocks per CU hide a block's serial steps better (C3, same box: 84.8 ms against
-// 88.8 with the latency kernel everywhere; one utterance 5.22 against 5.34 without it, the 5168-frame utterance 18.8
-// against 19.8).
+// Grids up to this many 64 x 128 tiles (one round of the chip at one block per CU) take the latency kernel; above it the
+// throughput kernel's three co-resident blocks per CU hide a block's serial steps better.  Same box, frame-rate
+// convolutions per step at thresholds 512 / 256 / 0: the 5168-frame utterance 2.02 / 1.96 / 2.28 ms, C2 (16
+// utterances) 2.97 / 2.40 / 2.36, C3 5.17 / 5.14 / -- (88.8 ms per step against 84.8 with the latency kernel everywhere).
 static long fr_max_blocks() {
 #ifdef VSP_EXPERIMENTS
   static long v = -1;
-  if (v < 0) { const char* e = getenv("VSP_FR_BLOCKS"); v = e ? atol(e) : 512; }
+  if (v < 0) { const char* e = getenv("VSP_FR_BLOCKS"); v = e ? atol(e) : 256; }
   return v;
 #else
-  return 512;
+  return 256;
 #endif
 }
 
