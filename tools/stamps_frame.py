@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where one conv_frame_f16s launch spends its time: tagged in-kernel stamps (wave 0 of every block) of the -DFR_STAMPS
 build (conv_mfma.hip).  Runs bench.py in-process for one step and reads the stamps of the VSP_STAMP_FRAME-th launch.
-usage (GPU box): VSP_LIB_PATH=build/frstamps/libvispeech_hip.so VSP_STAMP_FRAME=<n> python tools/stamps_frame.py [bench args]
+usage (tools/build_stamps.sh first; GPU box): VSP_LIB_PATH=build/frstamps/libvispeech_hip.so VSP_STAMP_FRAME=<n> python tools/stamps_frame.py [bench args]
 Tags: 1 start | 2 requests out | 3 first window in (wait + barrier) | 4 converted | per step: 10 top, 11 waited, 12 barrier,
 13 copies issued, 14 fragment reads + MFMAs issued, 15 next window converted | 30 loop done | 31 stores issued | 32 retired."""
 import ctypes as C
