@@ -306,7 +306,7 @@ int vsp_cl_conv1d(void* stream, int B, int T, int Cin, int Cout, int K, int dila
  * prologue: x * mask (lengths != NULL and mask_in) then leaky_relu(x, in_slope) when in_act; epilogue: act 0 none,
  * 1 relu, 2 WN gate tanh(rows [0, Cout/2)) * sigmoid(rows [Cout/2, Cout)) of interleaved 32-row tiles (then the output
  * has Cout / 2 rows; commons.py:100-107; no residual with the gate); then + res [B][rows][T], then * mask when mask_out.  K odd,
- * (K - 1) * dilation + 3 <= 64.  split_f16 = 1: fp32-accurate split-f16 MFMA (the default path of the library),
+ * (K - 1) * dilation + 3 <= 64, T % 4 == 0 or T == 1 (the cond(g) projections of one time step).  split_f16 = 1: fp32-accurate split-f16 MFMA (the default path of the library),
  * 0: f32 MFMA.  Reference: torch.nn.Conv1d as used in attentions.py:138-145, 277-285, modules.py:148-176. */
 int vsp_conv1d(void* stream, int B, int T, int Cin, int Cout, int K, int dilation, const float* x, const float* w_host,
                const float* bias_host, const int64_t* lengths, int mask_in, int in_act, float in_slope, int act,

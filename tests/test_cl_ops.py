@@ -167,3 +167,22 @@ def test_conv1d_matches_torch(lib, cin, cout, k, dil, act, b, t):
         if mask_out:
             y = y * torch.from_numpy(mask)
         assert rel_err(out.cpu().numpy(), y.numpy()) <= TOL, (split, mask_in, in_act, use_res, mask_out)
+
+
+@pytest.mark.parametrize("cin,cout,b", [(256, 3072, 1), (256, 512, 5), (192, 96, 2), (80, 200, 3), (1, 64, 1)])
+def test_conv1d_one_time_step_matches_torch(lib, cin, cout, b):
+    """A 1x1 convolution on ONE time step with a plain epilogue -- the cond(g) / cond_layer(g) projections of the speaker
+    embedding (reference modules.py:153-155, models.py:279, 507) -- takes the GEMV kernel (conv_t1_gemv): ragged channel
+    counts, a batch, row counts that are not a multiple of the block."""
+    r = np.random.Generator(np.random.PCG64(cin * 5 + cout + b))
+    x = r.standard_normal((b, cin, 1)).astype(np.float32)
+    w = (r.standard_normal((cout, cin, 1)) / np.sqrt(cin)).astype(np.float32)
+    bias = r.standard_normal(cout).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    out = torch.full((b, cout, 1), float("nan"), device="cuda")
+    rc = lib.vsp_conv1d(stream, b, 1, cin, cout, 1, 1, P(xd), w.ctypes.data_as(C.c_void_p), bias.ctypes.data_as(C.c_void_p),
+                        None, 0, 0, 0.0, 0, None, 0, 1, P(out))
+    assert rc == 0
+    y = F.conv1d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(bias).double())
+    assert rel_err(out.cpu().numpy(), y.numpy()) <= TOL

@@ -1582,7 +1582,8 @@ int vsp_conv1d(void* stream, int B, int T, int Cin, int Cout, int K, int dilatio
   if (!x || !w_host || !out || B < 0 || T < 0 || act < 0 || act > 2 || ((mask_in || mask_out) && !lengths) || (act == 2 && res))
     return VSP_ERR_ARG;
   if (Cin <= 0 || Cout <= 0 || K < 1 || !(K & 1) || dilation < 1 || (K - 1) * dilation + 3 > CONV_HALO ||
-      (act == 2 && Cout % 64) || (T & 3))          // (rows of T floats must stay 16-byte aligned for the vector staging)
+      (act == 2 && Cout % 64) || ((T & 3) && T != 1))   // (rows of T floats must stay 16-byte aligned for the vector staging;
+                                                        //  T = 1: the one-time-step projections, conv_t1_gemv)
     return VSP_ERR_UNSUPPORTED;
   if (B == 0 || T == 0) return VSP_OK;
   hipStream_t s = (hipStream_t)stream;
