@@ -7,7 +7,8 @@ import csv
 import re
 import sys
 
-FAM = re.compile(r"(g16_conv|g16_pair|g16_chain|g16_ups|conv1d_f32_mfma|conv_frame_f16s|conv_frame_splitk|attn_relpos_f16s)<([^>]*)>")
+FAM = re.compile(r"(g16_conv|g16_pair|g16_chain|g16_ups|conv1d_f32_mfma|conv_frame_f16s|conv_frame_splitk|attn_relpos_f16s|attn_pack_f16s)<([^>]*)>")
+MANGLED = re.compile(r"_ZN3vsp\d+(attn_relpos_f16s|attn_pack_f16s)I((?:Li[0-9]+E)+)E")
 tot = collections.OrderedDict()   # family -> counter -> sum
 cnt = collections.Counter()
 for path in sys.argv[1:]:
@@ -17,7 +18,11 @@ for path in sys.argv[1:]:
     half = ids[len(ids) // 2] if ids else 0
     seen = set()
     for r in rows:
-        m = FAM.search(r["Kernel_Name"])
+        name = r["Kernel_Name"]
+        ma = MANGLED.search(name)          # (rocprofv3 leaves some template instantiations mangled)
+        if ma:
+            name = f"{ma.group(1)}<{', '.join(x[2:-1] for x in re.findall(r'Li[0-9]+E', ma.group(2)))}>"
+        m = FAM.search(name)
         if not m or int(r["Dispatch_Id"]) < half:
             continue
         fam = f"{m.group(1)}<{m.group(2).replace(' ', '')}>"
