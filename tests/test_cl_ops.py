@@ -104,6 +104,31 @@ def test_cl_resblock_three_implementations(lib, c, k, dils, b, t):
     assert torch.equal(outs[0], outs[2]), float((outs[0] - outs[2]).abs().max())
 
 
+@pytest.mark.parametrize("k,dils", [(7, (1, 3, 5)), (11, (1, 5))])
+@pytest.mark.parametrize("b,t", [(3, 40000), (1, 190000)])
+def test_cl_resblock_persistent_pair_kernel_long_rows(lib, k, dils, b, t):
+    """The register-weights pair kernel (g16_rw, gen16_rw.hip: 32 channels, kernel 7 / 11) is persistent: one block per
+    CU walks a RUN of 192-column tiles, pipelined over three tiles in flight.  Time axes long enough that every block
+    gets several tiles (and runs that cross an utterance boundary), against torch's fp64 convolution and bit for bit
+    against the per-convolution path."""
+    c = 32
+    r = np.random.Generator(np.random.PCG64(k * 31 + t))
+    x = r.standard_normal((b, t, c)).astype(np.float32)
+    ws = [(r.standard_normal((c, c, k)) / np.sqrt(c * k)).astype(np.float32) for _ in range(2 * len(dils))]
+    bs = [r.standard_normal(c).astype(np.float32) * 0.1 for _ in range(2 * len(dils))]
+    xd = torch.from_numpy(x).cuda()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    darr = (C.c_int * len(dils))(*dils)
+    outs = []
+    for mode in (0, 1):
+        out = torch.full((b, t, c), float("nan"), device="cuda")
+        rc = lib.vsp_cl_resblock(stream, b, t, c, k, len(dils), darr, P(xd), host_ptrs(ws), host_ptrs(bs), mode, 3, P(out))
+        assert rc == 0, mode
+        outs.append(out.cpu())
+    assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
+    assert rel_err(outs[1].numpy(), torch_resblock(x, ws, bs, dils, k)) <= TOL
+
+
 def test_cl_ops_refuse_what_they_cannot_do(lib):
     x = torch.zeros(1, 8, 48, device="cuda")
     out = torch.zeros(1, 8, 48, device="cuda")

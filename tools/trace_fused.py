@@ -11,7 +11,7 @@ rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if 'conv_post' in r['Kernel_Name']]
 seg = rows[idx[-2] + 1: idx[-1] + 1]
-gen = [r for r in seg if any(k in r['Kernel_Name'] for k in ('g16_conv', 'g16_pair', 'g16_chain', 'g16_ups'))]
+gen = [r for r in seg if any(k in r['Kernel_Name'] for k in ('g16_conv', 'g16_pair', 'g16_chain', 'g16_ups', 'g16_rw'))]
 c0 = 512
 rates = [8, 8, 4, 2]; uk = [16, 16, 4, 4]; ks = [3, 7, 11]
 specs = []

@@ -1,0 +1,142 @@
+// Shared device helpers of the split-f16 vocoder kernels (gen16.hip, gen16_rw.hip): vector typedefs, the diagnostic
+// build switches, the MFMA / barrier / counted-wait wrappers and THE operand split (g16_split4) -- every generator
+// kernel splits with this one function, which is what keeps the ResBlock implementations bit-identical.
+#pragma once
+#include "kernels.h"
+
+#include <type_traits>
+#include <utility>
+
+namespace vsp {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// G16_DIAG: timing-only ablation builds (tools/ablate.sh; results WRONG by construction): bit 0 no MFMA, bit 1 no
+// weight DMA, bit 2 no barriers, bit 3 no epilogue memory traffic, bit 4 no window loads, bit 5 every weight slice
+// copied from the SAME source bytes (slice 0: L2-hot), bit 6 no vmcnt waits.  0 in the product build.
+#ifndef G16_DIAG
+#define G16_DIAG 0
+#endif
+
+// G16_STAMPS (diagnostic build, tools/stamps_g16.py): waves 0 and NWV/2 of every 97th block of the VSP_STAMP_G16-th
+// g16_conv launch record wall-clock stamps (s_memrealtime, 100 MHz) at their phase boundaries.
+#ifdef G16_STAMPS
+constexpr int G16_NSTAMP = 256, G16_NSAMPLE = 64;
+static __device__ unsigned long long g_g16_stamps[G16_NSAMPLE][G16_NSTAMP];
+static __device__ unsigned g_g16_stamp_count;
+#define G16_STAMP()                                                                     \
+  do {                                                                                  \
+    if (stamp_slot >= 0 && stamp_n < G16_NSTAMP - 1 && lane == 0)                       \
+      g_g16_stamps[stamp_slot][stamp_n] = __builtin_amdgcn_s_memrealtime();             \
+    ++stamp_n;                                                                          \
+  } while (0)
+#define G16_STAMPT(tag)                                                                 \
+  do {                                                                                  \
+    if (stamp_slot >= 0 && stamp_n < G16_NSTAMP - 1 && lane == 0)                       \
+      g_g16_stamps[stamp_slot][stamp_n] = (__builtin_amdgcn_s_memrealtime() & 0x00ffffffffffffffull) | ((unsigned long long)(tag) << 56); \
+    ++stamp_n;                                                                          \
+  } while (0)
+#else
+#define G16_STAMP() ((void)0)
+#define G16_STAMPT(tag) ((void)0)
+#endif
+
+constexpr int G16_HALO = 64;   // max (K-1)*dil
+constexpr int G16_OOR = 0x7ffffff0;   // byte offset outside every buffer descriptor: loads give 0, stores are dropped
+
+// one asm statement: the "memory" clobber keeps the compiler from moving LDS traffic across the barrier; LDS-DMA
+// and global loads stay in flight (no vmcnt here)
+#if G16_DIAG & 4
+#define G16_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define G16_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+// f32x4 MFMA wrapper (ablation bit 0 keeps the operands alive without the matrix instruction)
+#if G16_DIAG & 1
+#define G16_MFMA(a, b, c) ([&]() { asm volatile("" ::"v"(a), "v"(b)); return c; }())
+#else
+#define G16_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#endif
+
+// s_waitcnt vmcnt(N): "at most N vector-memory operations outstanding".  They retire in issue order, so N = the
+// number of operations issued AFTER the one that must have landed.  The count is an immediate: the callers pick
+// among the few values that occur (pieces of one slice, plus 0 / 1 / 2 window-load groups of NL loads).
+template <int N>
+__device__ __forceinline__ void g16_vmcnt() {
+  if constexpr ((G16_DIAG & 64) == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+template <int P, int NL>
+__device__ __forceinline__ void g16_vm_wait(bool slice_behind, int groups) {
+  if (groups == 0) { if (slice_behind) g16_vmcnt<P>(); else g16_vmcnt<0>(); }
+  else if (groups == 1) { if (slice_behind) g16_vmcnt<P + NL>(); else g16_vmcnt<NL>(); }
+  else { if (slice_behind) g16_vmcnt<P + 2 * NL>(); else g16_vmcnt<2 * NL>(); }
+}
+
+template <int N>
+__device__ __forceinline__ void g16_lgkmcnt() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+// ds_read_b128 the compiler's wait-count pass does not see: the main loop places its own counted lgkmcnt waits
+// (hipcc waits lgkmcnt(0) at the first use of a fragment requested in the previous loop iteration, which stalls
+// every step on the reads just issued).  LDS operations return in order, so "at most N outstanding" = everything
+// but the N youngest has arrived.  Every wait is followed by a sched_barrier: hipcc would otherwise hoist a
+// register-only MFMA across the asm wait.
+template <int OFF>
+__device__ __forceinline__ f16x8 g16_lds_read(unsigned addr) {
+  f16x8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <class F, int... I>
+__device__ __forceinline__ void g16_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void g16_for(F&& f) {
+  g16_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// leaky-relu + split of four fp32 values -> hi / lo f16x4.
+// Round 3: built from the fewest vector instructions that keep the split exact (18 per four values instead of 32):
+//   hi = x with the mantissa TRUNCATED to f16 precision: one v_and_b32 on the fp32 bits (0xffffe000); exactly
+//        representable in f16 over the normal range, so v_cvt_pkrtz_f16_f32 packs two of them in ONE instruction
+//        without rounding (and saturates at the largest finite f16 instead of producing inf);
+//   lo = (x - hi) * 2^11: the residual is exact in fp32 (no conversion back from f16); packed by v_cvt_pkrtz as well.
+// Truncation instead of round-to-nearest leaves |x - hi| <= 2^-10 |x| (one bit more than before): hi + lo keeps 21
+// bits of x instead of 22 -- 2^-21 relative per operand, below the fp32 accumulation noise of a 96 .. 2816-term dot
+// product (measured waveform error unchanged, 1e-6).  Every generator kernel splits with this one function, so the
+// three ResBlock implementations stay bit-identical.
+__device__ __forceinline__ void g16_split2(f32x2 x, f16x2& h, f16x2& l) {
+  const f32x2 hf = {__uint_as_float(__float_as_uint(x.x) & 0xffffe000u), __uint_as_float(__float_as_uint(x.y) & 0xffffe000u)};
+  const f32x2 lf = (x - hf) * 2048.f;
+  h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(hf.x, hf.y));
+  l = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(lf.x, lf.y));
+}
+__device__ __forceinline__ void g16_split4(const f32x4 v, float slope, bool act, f16x4& eh, f16x4& el) {
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    f32x2 x = {v[2 * k], v[2 * k + 1]};
+    if (act) {
+      const f32x2 y = x * slope;
+      asm("v_max_f32 %0, %1, %2" : "=v"(x.x) : "v"(x.x), "v"(y.x));   // leaky-relu = max(x, slope*x), 0 <= slope <= 1
+      asm("v_max_f32 %0, %1, %2" : "=v"(x.y) : "v"(x.y), "v"(y.y));
+    }
+    f16x2 xh, xl;
+    g16_split2(x, xh, xl);
+    eh[2 * k] = xh.x; eh[2 * k + 1] = xh.y;
+    el[2 * k] = xl.x; el[2 * k + 1] = xl.y;
+  }
+}
+__device__ __forceinline__ f32x4 g16_as_f32x4(const u32x4 v) {
+  return f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+}
+__device__ __forceinline__ u32x4 g16_as_u32x4(const f32x4 v) {
+  return u32x4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+}
+
+}  // namespace vsp

@@ -99,6 +99,10 @@ hipError_t launch_g16_chain(const ClChainArgs& a, int B, hipStream_t s);
 hipError_t launch_g16_conv(const ClConvArgs& a, int B, hipStream_t s);
 bool g16_pair_supported(int C, int K, int dil);
 hipError_t launch_g16_pair(const ClPairArgs& a, int B, hipStream_t s);
+// the same pair with the weights held in registers by persistent blocks (gen16_rw.hip: 32 channels, kernel 7 / 11);
+// launch_g16_pair routes there unless VSP_PAIR=ring asks for the LDS-ring kernel (second implementation, bit-identical)
+bool g16_rw_supported(int C, int K, int dil, int terms);
+hipError_t launch_g16_rw(const ClPairArgs& a, int B, hipStream_t s);
 size_t packed_g16_halfs(int rows, int Cin, int K);
 void pack_g16_weights(uint16_t* dst, int rows, int Cin, int K, const float* dense /* [rows][Cin][K] */);
 // mel[b][m][t] = log(max(sum_{f in [lo[m], hi[m])} basis[m][f] * spec[b][f][t], 1e-5))  (reference mel_processing.py:16-22, 73-82)
