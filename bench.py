@@ -9,12 +9,15 @@ batch of ~5 s utterances, phoneme/duration/F0/energy/noise supplied), one proces
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same args>`
 and relays rank 0's single JSON line; under torch.distributed.run (RANK / WORLD_SIZE in the environment) it is a
 rank.  Workloads:
-  C3 (default)  every rank runs its own 64-utterance shard (weak scaling, seeds 103 + rank);
+  C3 (default)  BASELINE.json's metric literally: ONE 64-utterance batch at 1 / 2 / 4 / 8 GPUs -- rank r synthesises
+                its `shard_range` slice of the same batch (strong scaling; the N = 1 line is the single-GPU headline);
+                `--weak` gives every rank its own 64 utterances instead (weak scaling, seeds 103 + rank);
   C4            ONE global batch of 256 utterances, rank r synthesises its `shard_range` slice (32 each at 8 GPUs;
-                strong scaling) through `sharding.infer_sharded`;
-both pad to the GLOBAL frame count (one int all-reduce MAX, SURVEY gotcha G6), broadcast the packed weights from
+                strong scaling);
+all pad to the GLOBAL frame count (one int all-reduce MAX, SURVEY gotcha G6), broadcast the packed weights from
 rank 0 over RCCL once before timing, and end every step with the gather of the waveforms on rank 0 -- the
-exchange the north star names.  value = valid samples of all ranks / max-over-ranks time.
+exchange the north star names.  value = valid samples of all ranks / max-over-ranks time; the line also carries the
+per-rank step times (min / max) and the gather's share of a step (a second timed pass without the gather).
 
 A step = one full infer() with all inputs resident in HBM.  The headline is timed with profiling OFF; the
 per-kernel-class event timing behind `roofline` comes from a second, untimed pass of `--profile-steps` steps.
@@ -62,6 +65,10 @@ def parse(argv=None):
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample", type=int, default=16, help="utterances of the batch timed on the CPU oracle")
     p.add_argument("--cpu-runs", type=int, default=3, help="timed CPU-oracle runs (the median is reported) after one warm-up run")
+    p.add_argument("--weak", action="store_true",
+                   help="C3 and the other per-rank workloads: every rank synthesises its OWN batch (weak scaling) instead of "
+                        "its shard_range slice of ONE batch (strong scaling, the default: BASELINE.json's metric is one "
+                        "64-utterance batch at 1 / 2 / 4 / 8 GPUs)")
     p.add_argument("--dist", action="store_true",
                    help="initialise torch.distributed (RCCL) even at --gpus 1: the weight broadcast, the frame-count "
                         "all-reduce and the waveform gather run through the collectives with one rank")
@@ -249,7 +256,7 @@ def main():
 
     # ---- the batch.  C4: one global batch, this rank's slice; otherwise one batch per rank
     wl = dict(WORKLOADS[args.workload])
-    sharded_global = args.workload == "C4"
+    sharded_global = args.workload == "C4" or (not args.weak and args.workload != "C5")   # (C5 is ONE utterance: replicas only)
     if args.batch:
         wl["batch"] = args.batch
     if not sharded_global:
@@ -316,6 +323,17 @@ def main():
         step()
     drain()
     dt = time.perf_counter() - t0
+    dt_rank = dt
+    # the gather's share of a step: the same K steps once more WITHOUT the exchange (untimed for `value`)
+    dt_nogather = None
+    if gatherer is not None:
+        keep, gatherer = gatherer, None
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        drain()
+        dt_nogather = time.perf_counter() - t1
+        gatherer = keep
 
     # ---- second, untimed pass: HIP events around every launch of the profiled classes (rank 0's numbers are reported)
     prof = {}
@@ -332,13 +350,18 @@ def main():
         if use_dist:
             dist.barrier()
 
-    tt = torch.tensor([dt, float(valid_samples)], dtype=torch.float64, device=dev)
+    tt = torch.tensor([dt, float(valid_samples), dt_nogather or dt], dtype=torch.float64, device=dev)
+    rank_ms = [dt_rank / args.steps * 1e3]
     if use_dist:
         mx = tt.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = tt.clone()
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        mn = tt.clone()
+        dist.all_reduce(mn, op=dist.ReduceOp.MIN)
         dt, total_valid = float(mx[0].item()), float(sm[1].item())
+        rank_ms = [float(mn[0].item()) / args.steps * 1e3, float(mx[0].item()) / args.steps * 1e3]
+        dt_nogather = float(mx[2].item())
     else:
         total_valid = float(valid_samples)
 
@@ -347,6 +370,9 @@ def main():
         value = total_valid * args.steps / dt
         audio_s = total_valid / 44100.0
         gen_mode = os.environ.get("VSP_GENERATOR", "f16s")
+        # (at one GPU the whole batch is that GPU's: the single-GPU headline line reads the same in both modes)
+        split_text = " per GPU" if (not sharded_global or (world == 1 and args.workload != "C4")) else \
+            (f", ONE batch split over {world} GPUs (shard_range)" if args.workload != "C4" else "")
         out = {
             "metric": "44.1kHz samples/sec", "value": value, "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -354,13 +380,17 @@ def main():
             "dtype": "f32 (split-f16 MFMA, 3-term)", "data": "synthetic",
             "rtf": (dt / args.steps) / audio_s,
             "config": {"workload": f"{args.workload}: {B_all} {WL_TEXT.get(args.workload, 'utterances')}"
-                                   f"{'' if sharded_global else ' per GPU'}, 44.1 kHz, hop 512, "
+                                   f"{split_text}, 44.1 kHz, hop 512, "
                                    f"{ {'all': 'phoneme/duration/F0/energy/noise supplied', 'duration': 'phoneme/duration/noise supplied, F0 and energy PREDICTED', 'none': 'phonemes + noise supplied, duration / F0 / energy PREDICTED'}[args.controls] }"
                                    ", random-init (synthetic) weights of configs/config.json",
                        "utterances_per_gpu": B, "global_batch": B_all * (1 if sharded_global else world),
                        "padded_frames": tf_global, "valid_samples_per_step": int(total_valid),
                        "parallelism": f"shard{world}", "generator": gen_mode, "controls": args.controls},
             "n_ranks_seen": n_ranks_seen,
+            "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
+            "gather": ({"bytes_into_rank0_per_step": int(4 * 512 * tf_global * (B_all * (1 if sharded_global else world) - B)),
+                        "ms_per_step_without_gather": dt_nogather / args.steps * 1e3,
+                        "share_of_step": max(0.0, 1.0 - dt_nogather / dt)} if use_dist else None),
             "collectives": (f"torch.distributed backend {dist.get_backend()}: weight-arena broadcast, frame-count all-reduce MAX, "
                             "waveform gather on rank 0 (side stream, persistent buffers)") if use_dist else "none (one process, no process group)",
         }

@@ -271,6 +271,15 @@ int vsp_rq_spline(void* stream, int64_t n, int nb, const float* x, const float* 
  * their noise argument is NULL; it replaces torch.randn_like (reference models.py:718, 240) for C callers and is not
  * bit-compatible with torch's generator. */
 int vsp_randn(void* stream, uint64_t seed, int64_t n, float* out);
+/* The same stream from element `first` on: out[i] = element first + i.  A shard [lo, hi) of a batch whose noise is
+ * drawn by the library passes first = lo * inter * Tf and gets exactly the elements the unsharded call would draw for
+ * those utterances. */
+int vsp_randn_at(void* stream, uint64_t seed, int64_t first, int64_t n, float* out);
+/* Where in that stream the noise tensor of vsp_decode / vsp_infer (noise == NULL) starts: element 0 of the context's
+ * [B][inter][Tf] tensor is stream element `first_element` (default 0).  A rank that synthesises utterances [lo, hi) of a
+ * global batch sets lo * inter * Tf (Tf = the GLOBAL padded frame count): the result no longer depends on the shard
+ * layout.  Sticky until changed; 0 restores the default.  (Added in round 4; ABI 4 callers are unaffected.) */
+int vsp_set_noise_offset(vsp_ctx* ctx, int64_t first_element);
 
 /* ---- mel spectrogram (reference mel_processing.py:73-112) --------------------------------- */
 /* The mel basis the reference takes from librosa.filters.mel(sampling_rate, n_fft, n_mels, fmin, fmax) with that

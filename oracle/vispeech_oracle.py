@@ -518,20 +518,22 @@ def philox4x32_10(counter: np.ndarray, key0: int, key1: int) -> np.ndarray:
     return np.stack(c, axis=1).astype(np.uint32)
 
 
-def philox_randn(seed: int, n: int) -> np.ndarray:
-    """What ``vsp_randn(seed)`` computes (vispeech_amd/csrc/misc.hip randn_kernel): element i = Box-Muller word i % 4
-    of counter (i // 4, 0, 0, 0), key = (seed lo, seed hi); uniforms from the top 24 bits, (x + 0.5) / 2^24."""
-    groups = (n + 3) // 4
+def philox_randn(seed: int, n: int, first: int = 0) -> np.ndarray:
+    """What ``vsp_randn_at(seed, first)`` computes (vispeech_amd/csrc/misc.hip randn_kernel): stream element i =
+    Box-Muller word i % 4 of counter (i // 4, 0, 0, 0), key = (seed lo, seed hi); uniforms from the top 23 bits,
+    (x + 0.5) / 2^23 (exact in fp32, strictly inside (0, 1)); returns elements first .. first + n - 1."""
+    g0 = first // 4
+    groups = (first + n + 3) // 4 - g0
     ctr = np.zeros((groups, 4), dtype=np.uint32)
-    q = np.arange(groups, dtype=np.uint64)
+    q = np.arange(groups, dtype=np.uint64) + np.uint64(g0)
     ctr[:, 0] = (q & np.uint64(0xFFFFFFFF)).astype(np.uint32)
     ctr[:, 1] = (q >> np.uint64(32)).astype(np.uint32)
     w = philox4x32_10(ctr, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
-    u = ((w >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+    u = ((w >> np.uint32(9)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 8388608.0)
     out = np.empty((groups, 4), dtype=np.float32)
     for p in range(2):
         rad = np.sqrt(np.float32(-2.0) * np.log(u[:, 2 * p]))
         ang = np.float32(6.283185307179586) * u[:, 2 * p + 1]
         out[:, 2 * p] = rad * np.cos(ang)
         out[:, 2 * p + 1] = rad * np.sin(ang)
-    return out.reshape(-1)[:n]
+    return out.reshape(-1)[first - 4 * g0: first - 4 * g0 + n]

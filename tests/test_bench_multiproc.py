@@ -32,12 +32,28 @@ def run_bench(*extra, gpus=2, backend="gloo"):
 
 
 def test_two_rank_bench_self_launches_on_one_gpu():
-    d = run_bench("--batch", "4")
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    """The default line answers BASELINE.json's metric literally: ONE batch (here 6 utterances instead of 64) split
+    shard_range-wise over the ranks -- global_batch is the single batch, not batch x ranks."""
+    d = run_bench("--batch", "6")
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["n_ranks_seen"] == 2 and "gloo" in d["collectives"]
-    assert d["config"]["utterances_per_gpu"] == 4 and d["config"]["parallelism"] == "shard2" and d["config"]["global_batch"] == 8
+    assert d["config"]["global_batch"] == 6 and d["config"]["utterances_per_gpu"] == 3 and d["config"]["parallelism"] == "shard2"
+    assert "ONE batch split over 2 GPUs" in d["config"]["workload"]
+    from vispeech_amd.synth import WORKLOADS, synth_batch
+    b = synth_batch(**dict(WORKLOADS["C3"], batch=6))
+    assert d["config"]["valid_samples_per_step"] == 512 * int(b["frame_lengths"].sum())      # the ONE batch, counted once
+    assert d["config"]["padded_frames"] == int(b["frame_lengths"].max())                     # global padding (G6)
     assert "cpu_baseline" not in d                            # timed on rank 0 at N = 1 only
     assert d["roofline"]["launches"] == 57 and d["roofline"]["attention"]["launches"] == 8
+    assert 0 < d["rank_ms_per_step"]["min"] <= d["rank_ms_per_step"]["max"] <= d["ms_per_step"] * 1.001
+    g = d["gather"]
+    assert g["bytes_into_rank0_per_step"] == 4 * 512 * d["config"]["padded_frames"] * 3 and 0.0 <= g["share_of_step"] < 1.0
+
+
+def test_weak_scaling_form_keeps_a_batch_per_rank():
+    d = run_bench("--batch", "4", "--weak")
+    assert d["scaling"] == "weak" and d["config"]["utterances_per_gpu"] == 4 and d["config"]["global_batch"] == 8
+    assert "per GPU" in d["config"]["workload"]
 
 
 def test_c4_global_batch_is_sharded_over_the_ranks():
@@ -58,5 +74,6 @@ def test_rccl_path_runs_on_hardware_with_one_rank():
     launched through the self-launch path: the parent never touches the GPU, the rank is a fresh child process."""
     d = run_bench("--dist", "--batch", "4", "--no-cpu-baseline", gpus=1, backend="nccl")
     assert d["n_gpus"] == 1 and d["n_ranks_seen"] == 1 and "nccl" in d["collectives"]
-    assert d["value"] > 0 and d["config"]["utterances_per_gpu"] == 4
+    assert d["value"] > 0 and d["config"]["utterances_per_gpu"] == 4 and d["config"]["global_batch"] == 4
+    assert "per GPU" in d["config"]["workload"]               # (one GPU: the headline line reads as before)
     assert d["roofline"]["launches"] == 57

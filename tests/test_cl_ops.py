@@ -63,6 +63,25 @@ def test_cl_conv1d_matches_torch(lib, cin, cout, k, dil, b, t):
         assert rel_err(out.cpu().numpy(), ref.numpy()) <= TOL, (slope, use_res)
 
 
+def test_cl_conv1d_small_amplitude_activations_stay_within_the_documented_bound(lib):
+    """the operand split keeps hi + lo = 21 bits of an operand over the f16 NORMAL range; activations below
+    2^-14 land in f16 subnormals and lose up to 2^-24 ABSOLUTE each (g16_common.h).  With every activation at ~1e-5 the
+    result is held to that bound: |err| <= 2^-24 sum|w| + 1e-5 max|ref|."""
+    cin, cout, k, t = 64, 64, 7, 300
+    r = np.random.Generator(np.random.PCG64(3))
+    x = (r.standard_normal((1, t, cin)) * 1e-5).astype(np.float32)
+    w = (r.standard_normal((cout, cin, k)) / np.sqrt(cin * k)).astype(np.float32)
+    bias = np.zeros(cout, dtype=np.float32)
+    out = torch.empty(1, t, cout, device="cuda")
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = lib.vsp_cl_conv1d(stream, 1, t, cin, cout, k, 1, P(torch.from_numpy(x).cuda()), w.ctypes.data_as(C.c_void_p),
+                           bias.ctypes.data_as(C.c_void_p), 1.0, None, 3, P(out))
+    assert rc == 0
+    ref = F.conv1d(torch.from_numpy(x).double().transpose(1, 2), torch.from_numpy(w).double(), padding=3).transpose(1, 2).numpy()
+    bound = 2.0 ** -24 * float(np.abs(w).sum(axis=(1, 2)).max()) + 1e-5 * float(np.abs(ref).max())
+    assert float(np.abs(out.cpu().numpy() - ref).max()) <= bound
+
+
 def torch_resblock(x, ws, bs, dils, k):
     y = torch.from_numpy(x).double().transpose(1, 2)
     for p, d in enumerate(dils):
@@ -153,7 +172,8 @@ def test_cl_ops_refuse_what_they_cannot_do(lib):
 
 @pytest.mark.parametrize("cin,cout,k,dil,act", [(192, 192, 1, 1, 0), (192, 384, 5, 1, 2), (1, 192, 3, 1, 0), (192, 1, 1, 1, 0),
                                                 (192, 2, 3, 1, 0), (80, 192, 5, 1, 1), (768, 192, 3, 1, 0), (192, 768, 3, 1, 1),
-                                                (96, 192, 1, 1, 0), (192, 128, 7, 2, 0), (33, 65, 3, 1, 1), (192, 384, 3, 3, 2)])
+                                                (96, 192, 1, 1, 0), (192, 128, 7, 2, 0), (33, 65, 3, 1, 1), (192, 384, 3, 3, 2),
+                                                (96, 384, 1, 1, 0)])
 @pytest.mark.parametrize("b,t", [(1, 4), (3, 60), (2, 128), (2, 132), (1, 488), (1, 1100), (2, 2600)])
 def test_conv1d_matches_torch(lib, cin, cout, k, dil, act, b, t):
     """The frame-rate convolution kernels with their fused prologue / epilogue on ragged channel and row counts, one-row
@@ -192,6 +212,31 @@ def test_conv1d_matches_torch(lib, cin, cout, k, dil, act, b, t):
         if mask_out:
             y = y * torch.from_numpy(mask)
         assert rel_err(out.cpu().numpy(), y.numpy()) <= TOL, (split, mask_in, in_act, use_res, mask_out)
+
+
+def test_conv1d_same_utterance_agrees_across_batch_sizes(lib):
+    """launch_conv picks the channel-split, the one-barrier-per-K-taps or the throughput kernel from the GRID
+    size, and the channel-split kernel sums in a different order -- the same utterance alone and inside a batch of 16
+    agrees to the stage tolerance, not bit for bit (documented in DESIGN.md: results are not bit-identical across batch
+    sizes or shard counts; every path is held to the same 1e-5 against the fp64 reference)."""
+    cin, cout, k, t = 192, 768, 3, 488
+    r = np.random.Generator(np.random.PCG64(77))
+    x = r.standard_normal((16, cin, t)).astype(np.float32)
+    w = (r.standard_normal((cout, cin, k)) / np.sqrt(cin * k)).astype(np.float32)
+    bias = r.standard_normal(cout).astype(np.float32)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    outs = []
+    for b in (1, 16):
+        xd = torch.from_numpy(x[:b]).cuda()
+        out = torch.full((b, cout, t), float("nan"), device="cuda")
+        rc = lib.vsp_conv1d(stream, b, t, cin, cout, k, 1, P(xd), w.ctypes.data_as(C.c_void_p), bias.ctypes.data_as(C.c_void_p),
+                            None, 0, 0, 0.0, 1, None, 0, 1, P(out))
+        assert rc == 0
+        outs.append(out.cpu().numpy()[0])
+    ref = torch.relu(F.conv1d(torch.from_numpy(x[:1]).double(), torch.from_numpy(w).double(), torch.from_numpy(bias).double(),
+                              padding=1)).numpy()[0]
+    assert rel_err(outs[0], ref) <= TOL and rel_err(outs[1], ref) <= TOL
+    assert rel_err(outs[0], outs[1]) <= TOL
 
 
 @pytest.mark.parametrize("cin,cout,b", [(256, 3072, 1), (256, 512, 5), (192, 96, 2), (80, 200, 3), (1, 64, 1)])

@@ -548,6 +548,35 @@ def test_library_noise_draw_is_the_documented_philox_stream(net, oracle, dims):
     assert rel_err(to_np(a[0]), ref["o"].numpy()) <= WAVE_TOL
 
 
+def test_library_noise_of_a_shard_does_not_depend_on_the_shard_layout(net, dims):
+    """a rank that synthesises utterances [lo, hi) of a global batch with library-drawn noise must draw ITS
+    part of the global [B, C, Tf] stream (vsp_randn_at / vsp_set_noise_offset), at any (unaligned) element offset; and a
+    Python caller of the one-call path has to name the seed (no silent seed 0)."""
+    from oracle.vispeech_oracle import philox_randn
+    eng = net._engine
+    whole = eng.randn(5, 4099)
+    for first, n in ((0, 17), (1, 64), (6, 1021), (4096, 3)):
+        part = eng.randn(5, n, first=first)
+        assert torch.equal(part, whole[first:first + n]), (first, n)
+    np.testing.assert_array_equal(philox_randn(5, 1021, first=6), philox_randn(5, 1027)[6:])
+    from vispeech_amd.synth import synth_batch
+    b = synth_batch(3, seed=12, mean_phonemes=8, std_phonemes=1, min_phonemes=6, max_phonemes=10, mean_frames=30, jitter_frames=5)
+    t = lambda a: torch.from_numpy(np.asarray(a)).to(net.device)
+    ctl = dict(duration_control=t(b["duration"]), pitch_control=t(b["f0"]), energy_control=t(b["energy"]))
+    full = net.infer(t(b["phonemes"]), t(b["lengths"]), sid=t(b["sid"]), noise_scale=0.667, noise_seed=77, **ctl)
+    tf = full[2][0].shape[2]
+    lo = 0
+    for hi in (1, 3):                                      # shards [0, 1) and [1, 3) under the global padding
+        sl = slice(lo, hi)
+        part = net.infer(t(b["phonemes"])[sl], t(b["lengths"])[sl], sid=t(b["sid"])[sl], noise_scale=0.667, noise_seed=77,
+                         t_f=tf, noise_offset=lo * dims.inter_channels * tf, **{k: v[sl] for k, v in ctl.items()})
+        assert torch.equal(part[2][1], full[2][1][sl]) and torch.equal(part[0], full[0][sl])
+        lo = hi
+    with pytest.raises(ValueError):
+        eng.infer_padded(t(b["phonemes"]), t(b["lengths"]), t(b["sid"]), tf, None, noise_scale=0.667,
+                         duration_ctl=ctl["duration_control"], pitch_ctl=ctl["pitch_control"], energy_ctl=ctl["energy_control"])
+
+
 def test_attention_operands_beyond_the_f16_range_stay_finite(net, dims):
     """the split-f16 attention packs q / k / v with fixed scales; magnitudes beyond the f16 range are clamped
     (documented in include/vispeech_hip.h) instead of turning rows into NaN."""

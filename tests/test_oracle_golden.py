@@ -131,3 +131,35 @@ def test_philox_restatement_known_answers():
     x = philox_randn(99, 200001)
     assert x.shape == (200001,) and abs(float(x.mean())) < 1e-2 and abs(float(x.std()) - 1) < 1e-2
     np.testing.assert_array_equal(x[:1000], philox_randn(99, 1000))      # a function of (seed, index) only
+    np.testing.assert_array_equal(x[1003:1500], philox_randn(99, 497, first=1003))   # ... from any stream offset
+    assert float(np.abs(x).max()) < 6.0                                   # uniforms strictly inside (0, 1): no inf
+
+
+def test_spectrogram_restatement_is_pinned_to_torch_stft():
+    """the reference's linear spectrogram (mel_processing.py:50-69) is torch.stft on a reflect-padded
+    signal + sqrt(re^2 + im^2 + 1e-6).  Its call form (no ``return_complex``) is rejected by the installed torch, so no
+    reference RUN can pin it; what can be pinned is the third-party routine it names: the oracle must equal
+    (a) ``torch.stft(..., return_complex=True)`` post-processed exactly as the reference does on the real view
+    (``.pow(2).sum(-1)``), argument for argument (mel_processing.py:63-66), and (b) an independent framing + numpy FFT of
+    the same definition (periodic Hann window, center=False, one-sided).  The mel BASIS stays unpinned (librosa absent)."""
+    import torch.nn.functional as F
+    from oracle.vispeech_oracle import spectrogram
+    r = np.random.Generator(np.random.PCG64(5))
+    for n_fft, hop, L in ((2048, 512, 2048 * 3 + 100), (1024, 256, 5000), (512, 128, 700)):
+        y = (r.standard_normal((2, L)) * 0.3).astype(np.float32)
+        got = spectrogram(y, n_fft, hop).numpy()
+        yt = torch.from_numpy(y)
+        pad = int((n_fft - hop) / 2)
+        yp = F.pad(yt.unsqueeze(1), (pad, pad), mode="reflect").squeeze(1)
+        st = torch.stft(yp, n_fft, hop_length=hop, win_length=n_fft, window=torch.hann_window(n_fft), center=False,
+                        pad_mode="reflect", normalized=False, onesided=True, return_complex=True)
+        ref = torch.sqrt(torch.view_as_real(st).pow(2).sum(-1) + 1e-6).numpy()
+        np.testing.assert_array_equal(got, ref)
+        ypn = np.pad(y.astype(np.float64), ((0, 0), (pad, pad)), mode="reflect")
+        n_frames = 1 + (ypn.shape[1] - n_fft) // hop
+        win = 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n_fft) / n_fft)          # periodic Hann
+        fr = np.stack([ypn[:, i * hop:i * hop + n_fft] * win for i in range(n_frames)], axis=2)   # [B, n_fft, frames]
+        spec = np.fft.rfft(fr, axis=1)
+        ind = np.sqrt(spec.real ** 2 + spec.imag ** 2 + 1e-6)
+        assert got.shape == ind.shape == (2, n_fft // 2 + 1, n_frames)
+        assert np.abs(got - ind).max() <= 2e-4 * ind.max()                        # fp32 FFT vs float64

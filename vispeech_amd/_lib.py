@@ -73,6 +73,8 @@ SIGNATURES = {
     "vsp_wn_layer_workspace_bytes": (_I64, [_P, _I, _I, _I]),
     "vsp_wn_layer": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I64]),
     "vsp_randn": (_I, [_P, _U64, _I64, _P]),
+    "vsp_randn_at": (_I, [_P, _U64, _I64, _I64, _P]),
+    "vsp_set_noise_offset": (_I, [_P, _I64]),
     "vsp_encoder_workspace_bytes": (_I64, [_P, _I, _I]),
     "vsp_encoder": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _I64]),
     "vsp_length_regulate": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),

@@ -935,7 +935,7 @@ static int decode_impl(vsp_ctx* ctx, hipStream_t s, Ws& ws, int B, int Tp, int T
   float* drawn = ws.f((size_t)B * inter * Tf);
   const bool live = !ws.dry && !ws.overflow;
   if (live && !noise && noise_scale != 0.f) {
-    r.chk(launch_randn(noise_seed, (long)B * inter * Tf, drawn, s), "randn");
+    r.chk(launch_randn(noise_seed, (long)ctx->noise_first, (long)B * inter * Tf, drawn, s), "randn");
     noise = drawn;
   }
   if (live) {
@@ -1213,9 +1213,17 @@ int vsp_wn_layer(vsp_ctx* ctx, void* stream, int which, int layer, int B, int T,
   return wn_layer_impl(ctx, (hipStream_t)stream, ws, which, layer, B, T, x, g, lengths, skip, accumulate);
 }
 
-int vsp_randn(void* stream, uint64_t seed, int64_t n, float* out) {
-  if (n < 0 || (n > 0 && !out)) return VSP_ERR_ARG;
-  return launch_randn(seed, (long)n, out, (hipStream_t)stream) == hipSuccess ? VSP_OK : VSP_ERR_HIP;
+int vsp_randn(void* stream, uint64_t seed, int64_t n, float* out) { return vsp_randn_at(stream, seed, 0, n, out); }
+
+int vsp_randn_at(void* stream, uint64_t seed, int64_t first, int64_t n, float* out) {
+  if (n < 0 || first < 0 || (n > 0 && !out)) return VSP_ERR_ARG;
+  return launch_randn(seed, (long)first, (long)n, out, (hipStream_t)stream) == hipSuccess ? VSP_OK : VSP_ERR_HIP;
+}
+
+int vsp_set_noise_offset(vsp_ctx* ctx, int64_t first_element) {
+  if (!ctx || first_element < 0) return ctx ? ctx->fail(VSP_ERR_ARG, "vsp_set_noise_offset: negative offset") : VSP_ERR_ARG;
+  ctx->noise_first = first_element;
+  return VSP_OK;
 }
 
 // ---------------------------------------------------------------------------------- spectrogram

@@ -1107,13 +1107,9 @@ static hipError_t launch_frame(const ConvArgs& a, int B, hipStream_t s) {
   constexpr int NF4 = CONV_CK * ((BN + (K == 1 ? 0 : FR_HALO)) / 4);
   constexpr size_t lds = (size_t)WI * G * ((NF4 + 64 * NW - 1) / (64 * NW)) * NW * 1024 + (size_t)RI * G * K * MT * WM * 4096;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  static bool attr_set = false;
+  static std::atomic<uint64_t> attr_done{0};
   auto kern = conv_frame_f16s<MT, NT, WM, WN, K, G, RI, WI>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, attr_done); e != hipSuccess) return e;
   dim3 grid((a.Nq + BN - 1) / BN, (a.M + BM - 1) / BM, B);
 #ifdef FR_STAMPS
   {  // stamps only in the VSP_STAMP_FRAME-th launch (0-based, counted over all conv_frame_f16s launches)
@@ -1145,14 +1141,9 @@ static hipError_t launch_tile(const ConvArgs& a, int B, hipStream_t s) {
   constexpr size_t lds = (size_t)CONV_CK * (BN + CONV_HALO) * sizeof(float) +
                          (RING ? (size_t)conv_ring_slots(MT, WM) * MT * WM * 4096 : 0);
   static_assert(lds <= 160 * 1024, "LDS budget (<= 80 KiB: two blocks per CU)");
-  static bool attr_set = false;
+  static std::atomic<uint64_t> attr_done{0};
   auto kern = conv1d_f32_mfma<MT, NT, WM, WN, F16S, RING>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, attr_done); e != hipSuccess) return e;
   dim3 grid((a.Nq + BN - 1) / BN, (a.M + BM - 1) / BM, B);
   hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, a);
   return hipGetLastError();
@@ -1395,13 +1386,9 @@ static hipError_t launch_splitk_g(const ConvArgs& a, int B, hipStream_t s) {
   constexpr int LWP = 32 + (K == 1 ? 0 : FR_HALO);
   constexpr size_t win = (size_t)2 * 4 * CONV_CK * LWP * 4, part = (size_t)4 * 2 * 16 * 64 * 4;
   constexpr size_t lds = win > part ? win : part;
-  static bool attr_set = false;
+  static std::atomic<uint64_t> attr_done{0};
   auto kern = conv_frame_splitk<K, GATE>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, attr_done); e != hipSuccess) return e;
   dim3 grid((a.Nq + 31) / 32, (a.M + 63) / 64, B);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
   return hipGetLastError();

@@ -110,7 +110,11 @@ __device__ __forceinline__ void g16_for(F&& f) {
 // Truncation instead of round-to-nearest leaves |x - hi| <= 2^-10 |x| (one bit more than before): hi + lo keeps 21
 // bits of x instead of 22 -- 2^-21 relative per operand, below the fp32 accumulation noise of a 96 .. 2816-term dot
 // product (measured waveform error unchanged, 1e-6).  Every generator kernel splits with this one function, so the
-// three ResBlock implementations stay bit-identical.
+// ResBlock implementations stay bit-identical.
+// Caveat: "exactly representable" holds over the f16 NORMAL range.  Below it (|x| < 2^-14 = 6.1e-5) the
+// packed hi is a subnormal f16 that keeps fewer than 11 bits while lo is still taken against the fp32-truncated value,
+// so hi + lo loses up to 2^-24 ABSOLUTE per operand there -- below the fp32 accumulation noise of any activation that
+// matters (vocoder activations are O(1e-2 .. 1)); tests/test_cl_ops.py keeps a small-amplitude case.
 __device__ __forceinline__ void g16_split2(f32x2 x, f16x2& h, f16x2& l) {
   const f32x2 hf = {__uint_as_float(__float_as_uint(x.x) & 0xffffe000u), __uint_as_float(__float_as_uint(x.y) & 0xffffe000u)};
   const f32x2 lf = (x - hf) * 2048.f;

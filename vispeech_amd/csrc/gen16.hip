@@ -349,13 +349,9 @@ static hipError_t launch_g16_tile(const ClConvArgs& a, int B, hipStream_t s) {
   constexpr int BT = 16 * NW * WN, MTB = MW * WM;
   constexpr size_t lds = (size_t)2 * 2 * 4 * (BT + G16_HALO) * 16 + (size_t)4 * MTB * 2048;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  static bool attr_set = false;
+  static std::atomic<uint64_t> attr_done{0};
   auto kern = g16_conv<MW, NW, WM, WN, TERMS>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, attr_done); e != hipSuccess) return e;
   const int nmt = a.phases * a.Cout / 16;
   if (nmt % MTB || a.Cin % 32) return hipErrorInvalidValue;
   dim3 grid((a.Nq + BT - 1) / BT, nmt / MTB, B);
@@ -842,13 +838,9 @@ static hipError_t launch_g16_pair_tile(ClPairArgs a, int B, hipStream_t s) {
   constexpr int BT = 32 * NWV;
   constexpr size_t lds = (size_t)2 * 4 * (BT + G16_HALO) * 16 + (size_t)NS * G * 2 * NCH * 2048;
   static_assert(lds <= (NWV == 8 ? 80 : 160) * 1024, "two 8-wave blocks or one 16-wave block per CU");
-  static bool attr_set = false;
+  static std::atomic<uint64_t> attr_done{0};
   auto kern = g16_pair<NCH, G, TERMS, NWV, NS>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, attr_done); e != hipSuccess) return e;
   const int R2 = BT - (a.K - 1);
   a.tiles = (a.T + R2 - 1) / R2;
   const long n = (long)a.tiles * B;
@@ -1181,13 +1173,9 @@ static hipError_t launch_g16_chain_tile(ClChainArgs a, int B, hipStream_t s) {
   constexpr int BT = 16 * NW * NWV;
   constexpr size_t lds = (size_t)NCH * 2 * 4 * (BT + G16_HALO) * 16 + (size_t)3 * G * 2 * NCH * 2048;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  static bool attr_set = false;
+  static std::atomic<uint64_t> attr_done{0};
   auto kern = g16_chain<NCH, NW, G, TERMS, NWV>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, attr_done); e != hipSuccess) return e;
   const int R = BT - 2 * a.halo;
   if (R < 32) return hipErrorInvalidValue;
   a.tiles = (a.T + R - 1) / R;

@@ -413,7 +413,8 @@ bool g16_rw_supported(int C, int K, int dil, int terms) {
 template <int K, bool ACC>
 static hipError_t launch_g16_rw_k(ClPairArgs a, int B, hipStream_t s) {
   auto kern = g16_rw<K, ACC>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RW_LDS);
+  static std::atomic<uint64_t> attr_done{0};
+  hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(kern), RW_LDS, attr_done);
   if (e != hipSuccess) return e;
   constexpr int R2 = RW_BT - (K - 1);
   a.tiles = (a.T + R2 - 1) / R2;

@@ -3,7 +3,23 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace vsp {
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is set per DEVICE: a process may hold contexts on several GPUs (vsp_create
+// takes a device index), so a launcher remembers it per (kernel, device) -- `done` is the launcher's static bit set, one
+// bit per device; safe to race (the attribute call is idempotent).
+inline hipError_t set_max_dynamic_lds(const void* kern, int bytes, std::atomic<uint64_t>& done) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+  e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+  return e;
+}
 
 // ------------------------------------------------------------------------------------------
 // conv1d as implicit GEMM on v_mfma_f32_32x32x2_f32 (exact f32 fmaf chain).
@@ -165,8 +181,8 @@ hipError_t launch_length_regulate(const float* x, long x_bs, long x_cs, const in
 // z_p = m_p + noise * exp(logs_p) * noise_scale ; x_mask[b][t] = t < len[b]
 hipError_t launch_reparam(const float* m_p, const float* logs_p, const float* noise, float noise_scale,
                           float* z_p, long n, hipStream_t s);
-// out[i] = standard normal draw i of the Philox4x32-10 stream keyed by `seed` (misc.hip)
-hipError_t launch_randn(uint64_t seed, long n, float* out, hipStream_t s);
+// out[i] = standard normal draw first + i of the Philox4x32-10 stream keyed by `seed` (misc.hip)
+hipError_t launch_randn(uint64_t seed, long first, long n, float* out, hipStream_t s);
 hipError_t launch_mask_u8(const int64_t* lengths, uint8_t* mask, int B, int T, hipStream_t s);
 // o[b][t] = tanh( sum_c sum_j w[c][j] * lrelu(x[b][c][t+j-pad], slope) )  (conv_post, no bias)
 hipError_t launch_conv_post(const float* x, long x_bs, long x_cs, const float* w, int C, int K, float slope,

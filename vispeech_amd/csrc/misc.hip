@@ -381,16 +381,18 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
   }
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
-__global__ void __launch_bounds__(256) randn_kernel(uint32_t k0, uint32_t k1, long n, float* __restrict__ out) {
-  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;   // counter = group of four elements
-  if (4 * q >= n) return;
+// `first` = index of out[0] in the stream: a shard of a larger tensor draws ITS elements (sharded batches do not depend on
+// the shard layout).  Uniforms: the top 23 bits, (x + 0.5) / 2^23 -- exact in fp32, strictly inside (0, 1).
+__global__ void __launch_bounds__(256) randn_kernel(uint32_t k0, uint32_t k1, long first, long n, float* __restrict__ out) {
+  const long q = (first >> 2) + (long)blockIdx.x * blockDim.x + threadIdx.x;   // counter = group of four stream elements
+  if (4 * q >= first + n) return;
   uint32_t w[4];
   philox4x32_10((uint32_t)(q & 0xffffffffu), (uint32_t)((unsigned long)q >> 32), 0u, 0u, k0, k1, w);
   float v[4];
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
-    const float u1 = ((float)(w[2 * p] >> 8) + 0.5f) * (1.f / 16777216.f);      // (0, 1): 24 bits, never 0
-    const float u2 = ((float)(w[2 * p + 1] >> 8) + 0.5f) * (1.f / 16777216.f);
+    const float u1 = ((float)(w[2 * p] >> 9) + 0.5f) * (1.f / 8388608.f);
+    const float u2 = ((float)(w[2 * p + 1] >> 9) + 0.5f) * (1.f / 8388608.f);
     const float rad = sqrtf(-2.f * logf(u1));
     float sn, cs;
     sincosf(6.283185307179586f * u2, &sn, &cs);
@@ -398,13 +400,17 @@ __global__ void __launch_bounds__(256) randn_kernel(uint32_t k0, uint32_t k1, lo
     v[2 * p + 1] = rad * sn;
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
-    if (4 * q + j < n) out[4 * q + j] = v[j];
+  for (int j = 0; j < 4; ++j) {
+    const long i = 4 * q + j - first;
+    if (i >= 0 && i < n) out[i] = v[j];
+  }
 }
-hipError_t launch_randn(uint64_t seed, long n, float* out, hipStream_t s) {
+hipError_t launch_randn(uint64_t seed, long first, long n, float* out, hipStream_t s) {
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(randn_kernel, dim3(cdiv((n + 3) / 4, 256)), dim3(256), 0, s, (uint32_t)(seed & 0xffffffffu),
-                     (uint32_t)(seed >> 32), n, out);
+  if (first < 0) return hipErrorInvalidValue;
+  const long groups = ((first + n + 3) >> 2) - (first >> 2);
+  hipLaunchKernelGGL(randn_kernel, dim3(cdiv(groups, 256)), dim3(256), 0, s, (uint32_t)(seed & 0xffffffffu),
+                     (uint32_t)(seed >> 32), first, n, out);
   return hipGetLastError();
 }
 
@@ -474,13 +480,8 @@ hipError_t launch_conv_post(const float* x, long x_bs, long x_cs, const float* w
                             float* o, long o_bs, int B, int T, hipStream_t s) {
   if (K > CP_MAXK || C > 32) return hipErrorInvalidValue;
   const size_t lds = ((size_t)C * (CP_TILE + 8) + (size_t)C * CP_MAXK) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_post_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(conv_post_kernel), 140 * 1024, attr_done); e != hipSuccess) return e;
   hipLaunchKernelGGL(conv_post_kernel, dim3(cdiv(T, CP_TILE), B), dim3(128), lds, s, x, x_bs, x_cs, w, C, K, slope,
                      o, o_bs, T);
   return hipGetLastError();

@@ -196,9 +196,16 @@ class Engine:
         return dict(Tf=int(Tf), Tdec=Tdec, o_buf=o_buf, out=out, ws=ws, max_len=max_len)
 
     def decode(self, enc: Mapping[str, torch.Tensor], Tf: int, noise: Optional[torch.Tensor], noise_scale: float,
-               max_len: Optional[int] = None, noise_seed: int = 0, bufs=None) -> Dict[str, torch.Tensor]:
-        """``noise`` None with ``noise_scale`` != 0: the library draws it on the device (``vsp_randn(noise_seed)``).
+               max_len: Optional[int] = None, noise_seed: Optional[int] = None, bufs=None,
+               noise_offset: int = 0) -> Dict[str, torch.Tensor]:
+        """``noise`` None with ``noise_scale`` != 0: the library draws it on the device -- elements ``noise_offset`` ..
+        of ``vsp_randn(noise_seed)``; the caller must then name the seed (a silent default would hand out the same
+        "random" sample on every call).  ``noise_offset``: a shard [lo, hi) of a global batch passes lo * inter * Tf so
+        that its utterances get the noise they would get unsharded.
         ``bufs``: a ``decode_buffers`` result for the same ``Tf`` / ``max_len`` (else allocated here)."""
+        if noise is None and float(noise_scale) != 0.0 and noise_seed is None:
+            raise ValueError("pass noise or an explicit noise_seed (noise_scale != 0)")
+        noise_seed = 0 if noise_seed is None else noise_seed
         d = self.dims
         B, _, Tp = enc["x_var"].shape
         inter = d.inter_channels
@@ -210,6 +217,7 @@ class Engine:
             if tuple(noise.shape) != (B, inter, Tf):
                 raise ValueError(f"noise must be [{B},{inter},{Tf}], got {tuple(noise.shape)}")
         with torch.cuda.device(self.device):
+            _lib.check(self.lib.vsp_set_noise_offset(self.ctx, int(noise_offset)), self.ctx, "vsp_set_noise_offset")
             rc = self.lib.vsp_decode(self.ctx, self._stream(), B, Tp, Tf, -1 if max_len is None else Tdec,
                                      _ptr(enc["x_var"]), _ptr(enc["g"]), _ptr(enc["cum_dur"]),
                                      _ptr(enc["frame_lengths"]), _ptr(noise), int(noise_seed) & (2**64 - 1),
@@ -223,9 +231,14 @@ class Engine:
     # ------------------------------------------------------------------ per-stage entry points
     def infer_padded(self, phonemes, lengths, sid, tf_pad: int, noise, noise_scale: float = 1.0, max_len=None,
                      duration_ctl=None, pitch_ctl=None, energy_ctl=None, duration_scale: float = 1.0,
-                     pitch_scale: float = 1.0, energy_scale: float = 1.0, noise_seed: int = 0) -> Dict[str, torch.Tensor]:
+                     pitch_scale: float = 1.0, energy_scale: float = 1.0, noise_seed: Optional[int] = None,
+                     noise_offset: int = 0) -> Dict[str, torch.Tensor]:
         """``vsp_infer``: the whole path in ONE call and without the host read of the frame counts, for
-        callers that know an upper bound ``tf_pad`` of the frame count (supplied durations / fixed max_len)."""
+        callers that know an upper bound ``tf_pad`` of the frame count (supplied durations / fixed max_len).
+        ``noise`` None with ``noise_scale`` != 0 needs an explicit ``noise_seed`` (see ``decode``)."""
+        if noise is None and float(noise_scale) != 0.0 and noise_seed is None:
+            raise ValueError("pass noise or an explicit noise_seed (noise_scale != 0)")
+        noise_seed = 0 if noise_seed is None else noise_seed
         ph = _dev_i64(phonemes, self.device)
         B, Tp = ph.shape
         ln, sd = _dev_i64(lengths, self.device), _dev_i64(sid, self.device)
@@ -246,6 +259,7 @@ class Engine:
         fl = torch.empty(B, dtype=torch.int64, device=self.device)
         ws = self._workspace("infer", self.lib.vsp_infer_workspace_bytes(self.ctx, B, Tp, Tf))
         with torch.cuda.device(self.device):
+            _lib.check(self.lib.vsp_set_noise_offset(self.ctx, int(noise_offset)), self.ctx, "vsp_set_noise_offset")
             rc = self.lib.vsp_infer(self.ctx, self._stream(), B, Tp, Tf, -1 if max_len is None else Tdec,
                                     _ptr(ph), _ptr(ln), _ptr(sd), _ptr(ctl[0]), _ptr(ctl[1]), _ptr(ctl[2]),
                                     float(duration_scale), float(pitch_scale), float(energy_scale), _ptr(nz),
@@ -285,12 +299,13 @@ class Engine:
         _lib.check(rc, self.ctx, "vsp_wn_layer")
         return x, sk
 
-    def randn(self, seed: int, *shape) -> torch.Tensor:
-        """``vsp_randn``: the library's own standard-normal stream (Philox4x32-10 keyed by ``seed``)."""
+    def randn(self, seed: int, *shape, first: int = 0) -> torch.Tensor:
+        """``vsp_randn_at``: elements ``first`` .. of the library's own standard-normal stream (Philox4x32-10 keyed by
+        ``seed``)."""
         out = self._f(*shape)
         with torch.cuda.device(self.device):
-            rc = self.lib.vsp_randn(self._stream(), int(seed) & (2**64 - 1), out.numel(), _ptr(out))
-        _lib.check(rc, self.ctx, "vsp_randn")
+            rc = self.lib.vsp_randn_at(self._stream(), int(seed) & (2**64 - 1), int(first), out.numel(), _ptr(out))
+        _lib.check(rc, self.ctx, "vsp_randn_at")
         return out
 
     def encoder(self, which: int, x, lengths) -> torch.Tensor:

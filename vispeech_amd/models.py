@@ -118,11 +118,12 @@ class SynthesizerTrn:
     @torch.no_grad()
     def infer(self, phonemes, phonemes_lengths, sid=None, noise_scale=1, max_len=None, energy_control=None,
               pitch_control=None, duration_control=None, *, noise: Optional[torch.Tensor] = None,
-              t_f: Optional[int] = None, noise_seed: Optional[int] = None):
+              t_f: Optional[int] = None, noise_seed: Optional[int] = None, noise_offset: int = 0):
         """Reference models.py:672-722.  ``noise`` (keyword-only, optional) replaces the
         ``torch.randn_like`` draw of models.py:718 so runs can be reproduced; without it the draw is
         ``torch.randn`` on the GPU (torch's generator, as in the reference) unless ``noise_seed`` is given: then the
-        library draws it itself (``vsp_randn``, what a C caller gets).  ``t_f`` pads the frame
+        library draws it itself (``vsp_randn``, what a C caller gets) from stream element ``noise_offset`` on (a shard
+        [lo, hi) of a global batch passes lo * inter_channels * t_f: same noise as unsharded).  ``t_f`` pads the frame
         axis to a global maximum for sharded batches (SURVEY gotcha G6).  Returns
         ``(o, x_mask, (z, z_p, m_p, logs_p), duration, F0, energy)``."""
         eng = self._engine
@@ -150,7 +151,8 @@ class SynthesizerTrn:
         ns = float(noise_scale)
         if noise is None and ns != 0.0 and noise_seed is None:
             noise = torch.randn(B, self.dims.inter_channels, Tf, dtype=torch.float32, device=eng.device)
-        dec = eng.decode(enc, Tf, noise, ns, max_len, noise_seed=0 if noise_seed is None else int(noise_seed), bufs=bufs)
+        dec = eng.decode(enc, Tf, noise, ns, max_len, noise_seed=0 if noise_seed is None else int(noise_seed), bufs=bufs,
+                         noise_offset=int(noise_offset))
         duration = duration_control if d_t is not None else enc["duration"].view(B, 1, Tp)
         return (dec["o"], dec["x_mask"], (dec["z"], dec["z_p"], dec["m_p"], dec["logs_p"]), duration, enc["F0"],
                 enc["energy"])

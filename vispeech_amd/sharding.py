@@ -175,7 +175,9 @@ def infer_sharded(net, phonemes, lengths, sid, *, noise: Optional[torch.Tensor] 
     ``infer_kwargs``, noise [B,C,Tf_global]); tensors are sliced along the batch axis here.
     ``frame_counts`` (optional, host ints per utterance) lets ranks agree on the global frame
     count without communication; otherwise it is the all-reduce MAX of the local maxima that
-    ``net.infer`` reports.  Returns (o_full [B,1,S] on ``dst`` else None, local result tuple)."""
+    ``net.infer`` reports.  With ``noise_seed`` in ``infer_kwargs`` instead of ``noise`` the library draws the noise: this
+    rank then draws ITS utterances' part of the global [B, C, Tf] stream (``noise_offset`` = lo * C * Tf), so the
+    result does not depend on the shard layout.  Returns (o_full [B,1,S] on ``dst`` else None, local result tuple)."""
     world = _world(group)
     rank = dist.get_rank(group) if _active() else 0
     B = phonemes.shape[0]
@@ -191,6 +193,8 @@ def infer_sharded(net, phonemes, lengths, sid, *, noise: Optional[torch.Tensor] 
     else:
         raise ValueError("pass frame_counts or noise so that all ranks pad to the same frame count")
     t_f = global_max(t_f, phonemes.device, group)
+    if noise is None and kw.get("noise_seed") is not None:
+        kw["noise_offset"] = lo * int(net.dims.inter_channels) * t_f
     out = net.infer(phonemes[sl], lengths[sl], sid=sid[sl], noise=None if noise is None else noise[sl], t_f=t_f, **kw)
     shards = gather_batch(out[0], dst=dst, group=group, counts=shard_counts(B, world))
     full = torch.cat(shards, dim=0) if shards is not None else None
