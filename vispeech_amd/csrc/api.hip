@@ -136,11 +136,18 @@ struct Run {
     }
   }
   // channels-last split-f16 conv: x [B][T_in][Cin] -> out rows of Cout
+  // x_img / o_img (round 4): the input read from / the result (also, or with out == NULL only) written as an OPERAND
+  // IMAGE (kernels.h ClConvArgs): a ResBlock's intermediate lives in HBM as the next convolution's split, activated
+  // window planes and reaches its LDS by LDS-DMA, without conversion arithmetic in the consumer.
   void clconv(const ClConv& L, const float* x, long x_bs, float* out, long o_bs, const float* res, long r_bs, int T_in,
-              int Nq, int T_store, float in_slope, bool acc_prev, float div, int B) {
+              int Nq, int T_store, float in_slope, bool acc_prev, float div, int B, const uint16_t* x_img = nullptr,
+              uint16_t* o_img = nullptr) {
     if (dry() || !ok()) return;
     ClConvArgs a;
     std::memset(&a, 0, sizeof a);
+    a.x_img = x_img; a.xi_bs = (long)cl_img_halfs(L.Cin, T_in); a.xi_tpad = cl_img_tpad(T_in);
+    a.o_img = o_img; a.oi_bs = (long)cl_img_halfs(L.Cout, T_store); a.oi_tpad = cl_img_tpad(T_store);
+    a.oi_slope = 0.1f;                                 // modules.LRELU_SLOPE: what every ResBlock convolution applies to its input
     a.x = x; a.x_bs = x_bs; a.x_ts = L.Cin;
     a.wh = reinterpret_cast<const uint16_t*>(A(L.wg));
     a.bias = A((size_t)L.b);
@@ -434,6 +441,17 @@ void run_generator_cl(Run& r, int B, int T, T3 z, const int64_t* in_lengths, con
   }
   float* buf[5];
   for (auto& bptr : buf) bptr = r.ws.f((size_t)B * mx);
+  // the operand image of a ResBlock intermediate on the stages that run one launch per convolution (>= 128 channels)
+  size_t mx_img = 0;
+  {
+    long t = T;
+    for (int i = 0; i < c.n_upsamples; ++i) {
+      t *= c.upsample_rates[i];
+      const int chi = c0 >> (i + 1);
+      if (chi >= 128 && chi % 32 == 0) mx_img = std::max(mx_img, cl_img_halfs(chi, (int)t) / 2);
+    }
+  }
+  uint16_t* timg = (r.ctx->t_img && mx_img && r.ctx->gen_mode == 1) ? reinterpret_cast<uint16_t*>(r.ws.f((size_t)B * mx_img)) : nullptr;
   // the channels-last kernels address one utterance's tensor with 32-bit byte offsets (buffer descriptors)
   if (mx * sizeof(float) >= (size_t)1 << 31) {
     if (r.rc == VSP_OK)
@@ -477,6 +495,9 @@ void run_generator_cl(Run& r, int B, int T, T3 z, const int64_t* in_lengths, con
       const float* xin = buf[cur] + (size_t)b0 * xbs;
       float *xu = XU + (size_t)b0 * bs, *t1 = T1 + (size_t)b0 * bs, *ya = YA + (size_t)b0 * bs, *xs = XS + (size_t)b0 * bs;
       r.clconv(U, xin, xbs, xu, bs, nullptr, 0, (int)Tn, (int)Tn + 1, (int)Tout, 0.1f, false, 1.f, nb);
+      // stages that run one launch per convolution hand the pair's intermediate over as an operand image
+      uint16_t* ti = (timg && ch >= 128 && ch % 32 == 0) ? timg + (size_t)b0 * cl_img_halfs(ch, (int)Tout) : nullptr;
+      if (ti && !r.dry() && r.ok()) r.chk(launch_cl_img_zero_pads(ti, nb, ch, (int)Tout, r.s), "cl_img_zero_pads");
       for (int j = 0; j < nk; ++j) {
         const ResBlockW& rb = m.rbs[i * nk + j];
         const int nd = (int)rb.dil.size();
@@ -504,9 +525,11 @@ void run_generator_cl(Run& r, int B, int T, T3 z, const int64_t* in_lengths, con
             r.clchain(rb, ch, yin, yout, bs, (int)Tout, last && j > 0, div, nb, d, 1);
           } else {
             const float* yin = d == 0 ? xu : ya;
-            r.clconv(rb.h1[d], yin, bs, t1, bs, nullptr, 0, (int)Tout, (int)Tout, (int)Tout, 0.1f, false, 1.f, nb);
+            const bool img = ti != nullptr && rb.k >= 3;
+            r.clconv(rb.h1[d], yin, bs, img ? nullptr : t1, bs, nullptr, 0, (int)Tout, (int)Tout, (int)Tout, 0.1f, false, 1.f,
+                     nb, nullptr, img ? ti : nullptr);
             r.clconv(rb.h2[d], t1, bs, last ? xs : ya, bs, yin, bs, (int)Tout, (int)Tout, (int)Tout, 0.1f,
-                     last && j > 0, div, nb);
+                     last && j > 0, div, nb, img ? ti : nullptr, nullptr);
           }
         }
       }
@@ -562,6 +585,7 @@ int vsp_create(const vsp_config* cfg, int device, vsp_ctx** out) {
     want_f16 = !strcmp(e, "f16");
   }
   if (const char* e = getenv("VSP_FUSE_PAIRS")) ctx->fuse_pairs = atoi(e) != 0;
+  if (const char* e = getenv("VSP_TIMG")) ctx->t_img = atoi(e) != 0;   // 0: ResBlock intermediates as fp32 tensors (second implementation)
   if (const char* e = getenv("VSP_CHAIN")) ctx->chain_mask = atoi(e);
 #ifdef VSP_EXPERIMENTS
   if (const char* e = getenv("VSP_ATT_KSPLIT")) ctx->att_ksplit = atoi(e);
@@ -1653,6 +1677,11 @@ int vsp_cl_resblock(void* stream, int B, int T, int C, int K, int n_pairs, const
   if (e == hipSuccess && mode != 2) e = t1.alloc(el * 4);
   if (e == hipSuccess && mode != 2) e = ya.alloc(el * 4);
   if (e == hipSuccess && mode != 2) e = yb.alloc(el * 4);
+  DevBuf timg;
+  if (e == hipSuccess && mode == 0 && terms == 3 && K >= 3) {
+    e = timg.alloc((size_t)B * cl_img_halfs(C, T) * 2);
+    if (e == hipSuccess) e = launch_cl_img_zero_pads(static_cast<uint16_t*>(timg.p), B, C, T, s);
+  }
   if (e != hipSuccess) return op_rc(e);
   if (mode == 2) {
     ClChainArgs a;
@@ -1676,11 +1705,19 @@ int vsp_cl_resblock(void* stream, int B, int T, int C, int K, int n_pairs, const
         a.C = C; a.K = K; a.dil = dilations[p]; a.T = T; a.slope = 0.1f; a.acc_prev = 0; a.div = 1.f; a.terms = terms;
         e = launch_g16_pair(a, B, s);
       } else {
-        e = launch_g16_conv(cl_conv_args(yin, T, C, C, K, dilations[p], w[2 * p], bias[2 * p], 0.1f, nullptr, terms,
-                                         static_cast<float*>(t1.p)), B, s);
-        if (e == hipSuccess)
-          e = launch_g16_conv(cl_conv_args(static_cast<const float*>(t1.p), T, C, C, K, 1, w[2 * p + 1], bias[2 * p + 1], 0.1f,
-                                           yin, terms, yout), B, s);
+        // one launch per convolution; the intermediate as an operand image where the kernels take one (terms 3, K >= 3):
+        // the path the >= 128-channel stages of the generator run
+        const bool img = terms == 3 && K >= 3 && timg.p;
+        ClConvArgs a1 = cl_conv_args(yin, T, C, C, K, dilations[p], w[2 * p], bias[2 * p], 0.1f, nullptr, terms,
+                                     img ? nullptr : static_cast<float*>(t1.p));
+        ClConvArgs a2 = cl_conv_args(static_cast<const float*>(t1.p), T, C, C, K, 1, w[2 * p + 1], bias[2 * p + 1], 0.1f, yin,
+                                     terms, yout);
+        if (img) {
+          a1.o_img = static_cast<uint16_t*>(timg.p); a1.oi_bs = (long)cl_img_halfs(C, T); a1.oi_tpad = cl_img_tpad(T); a1.oi_slope = 0.1f;
+          a2.x_img = a1.o_img; a2.xi_bs = a1.oi_bs; a2.xi_tpad = a1.oi_tpad;
+        }
+        e = launch_g16_conv(a1, B, s);
+        if (e == hipSuccess) e = launch_g16_conv(a2, B, s);
       }
       yin = yout;
     }

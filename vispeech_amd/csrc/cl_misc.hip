@@ -88,4 +88,22 @@ hipError_t launch_conv_post_cl(const float* x, long x_bs, int x_ts, const float*
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Operand images (kernels.h ClConvArgs::x_img / o_img): the producer writes the data rows [PADF, PADF + T) of every
+// plane; the CL_IMG_PADF rows in front and the CL_IMG_PADB rows behind must read as zero (the convolution's zero padding
+// and the last tile's overshoot).  One block per plane: planes = B * (C / 32) * 2 * 4.
+__global__ void __launch_bounds__(256) cl_img_zero_pads_kernel(uint4* __restrict__ img, int T, int tpad) {
+  uint4* pl = img + (size_t)blockIdx.x * tpad;
+  const uint4 z = {0u, 0u, 0u, 0u};
+  for (int r = threadIdx.x; r < CL_IMG_PADF; r += 256) pl[r] = z;
+  for (int r = CL_IMG_PADF + T + threadIdx.x; r < tpad; r += 256) pl[r] = z;
+}
+hipError_t launch_cl_img_zero_pads(uint16_t* img, int B, int C, int T, hipStream_t s) {
+  if (B <= 0 || C % 32 || T <= 0 || (reinterpret_cast<uintptr_t>(img) & 15)) return hipErrorInvalidValue;
+  const long planes = (long)B * (C / 32) * 8;
+  hipLaunchKernelGGL(cl_img_zero_pads_kernel, dim3((unsigned)planes), dim3(256), 0, s, reinterpret_cast<uint4*>(img), T,
+                     cl_img_tpad(T));
+  return hipGetLastError();
+}
+
 }  // namespace vsp

@@ -15,6 +15,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // G16_DIAG: timing-only ablation builds (tools/ablate.sh; results WRONG by construction): bit 0 no MFMA, bit 1 no
 // weight DMA, bit 2 no barriers, bit 3 no epilogue memory traffic, bit 4 no window loads, bit 5 every weight slice
@@ -47,6 +48,7 @@ static __device__ unsigned g_g16_stamp_count;
 #endif
 
 constexpr int G16_HALO = 64;   // max (K-1)*dil
+constexpr int G16_IMG_PADF = CL_IMG_PADF;   // operand images: zero rows in front of time 0 (>= the largest padding)
 constexpr int G16_OOR = 0x7ffffff0;   // byte offset outside every buffer descriptor: loads give 0, stores are dropped
 
 // one asm statement: the "memory" clobber keeps the compiler from moving LDS traffic across the barrier; LDS-DMA

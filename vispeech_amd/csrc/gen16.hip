@@ -64,13 +64,23 @@ void pack_g16_weights(uint16_t* dst, int rows, int Cin, int K, const float* dens
 }
 
 
+// (out == NULL -- an image-only result -- gets an empty descriptor: loads give 0, stores are dropped)
+__device__ __forceinline__ float* g16_out_base(const ClConvArgs& a, int b) {
+  return a.out ? a.out + (size_t)b * a.o_bs : nullptr;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Single convolution (and polyphase transposed convolution).  Block = WM x WN waves; a wave owns MW m-tiles
 // (16 output rows each) x NW n-tiles (16 time columns each).  Contraction runs chunk-major: for each 32-channel
 // chunk, for each tap: one "step" = MW*NW*3 MFMAs per wave, NW sub-steps of MW*3.
 // The window is double-buffered per chunk: chunk c + 1 is converted and written during the MEM phase of chunk c's
 // last step (no exposed chunk transition).
-template <int MW, int NW, int WM, int WN, int TERMS>
+// XIN (round 4): the input is a producer-written OPERAND IMAGE (ClConvArgs::x_img: leaky-relu applied, hi / lo split, in
+// the window's own plane layout) instead of the fp32 tensor: a chunk's window goes HBM -> LDS by LDS-DMA -- every wave
+// copies one (image, plane) of it in NL pieces of 64 rows -- with no conversion arithmetic, no staging registers and,
+// above all, without the vmcnt(0) hipcc puts in front of the staged registers' first use, which drained the weight ring
+// once per chunk.  The same arithmetic on the same bits: results are bit-identical to the fp32-input form.
+template <int MW, int NW, int WM, int WN, int TERMS, bool XIN = false>
 __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
   constexpr int NWV = WM * WN, NTH = 64 * NWV;
   constexpr int BT = 16 * NW * WN;              // time columns per block
@@ -121,10 +131,10 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.x) + (size_t)b * a.x_bs, 0, a.T_in * a.x_ts * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
-      a.out + (size_t)b * a.o_bs, 0, a.T_store * a.o_ts * 4, 0x00020000);
+      g16_out_base(a, b), 0, a.out ? a.T_store * a.o_ts * 4 : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rr_ = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.res ? a.res : a.out) + (size_t)b * (a.res ? a.r_bs : a.o_bs), 0,
-      a.T_store * (a.res ? a.r_ts : a.o_ts) * 4, 0x00020000);
+      a.res ? const_cast<float*>(a.res) + (size_t)b * a.r_bs : g16_out_base(a, b), 0,
+      a.res ? a.T_store * a.r_ts * 4 : (a.out ? a.T_store * a.o_ts * 4 : 0), 0x00020000);
 
   // ---- window staging: 16 consecutive lanes write 128 contiguous bytes of one plane (conflict-free)
   const int g16 = tid >> 4, kq_s = g16 & 3, row_s = (g16 >> 2) * 8 + ((tid >> 1) & 7), half_s = tid & 1;
@@ -152,6 +162,20 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
       *reinterpret_cast<f16x4*>(dst0 + u * RPS * 16) = eh;
       if constexpr (TERMS == 3) *reinterpret_cast<f16x4*>(dst0 + u * RPS * 16 + XIMG) = el;
     }
+  };
+  // ---- XIN: the window chunk by LDS-DMA.  Image layout [chunk][hi | lo][plane][padded time][8 halfs] (zero rows in
+  //      front of time 0 and behind time T - 1: the convolution's zero padding and the last tile's overshoot); wave w
+  //      copies (image w / 4, plane w % 4): NL pieces of 64 rows, each 1 KiB contiguous on both sides.
+  [[maybe_unused]] auto xi_issue = [&](int chunk) {
+    static_assert(!XIN || (NWV == 8 && WR == NL * 64 && TERMS == 3), "one (image, plane) per wave, whole 64-row pieces");
+    const int img = wave >> 2, plane = wave & 3;
+    const size_t row0 = (((size_t)chunk * 2 + img) * 4 + plane) * a.xi_tpad + (size_t)(G16_IMG_PADF + t0 - a.pad);
+    const uint4* gp0 = reinterpret_cast<const uint4*>(a.x_img + (size_t)b * a.xi_bs) + row0 + lane;
+    char* lp0 = Xw + (chunk & 1) * XBUF + img * XIMG + plane * PL;
+#pragma unroll
+    for (int u = 0; u < NL; ++u)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp0 + u * 64),
+                                       (__attribute__((address_space(3))) void*)(lp0 + u * 1024), 16, 0, 0);
   };
   // ---- weight slices by LDS-DMA: slice (chunk, tap) = NBLK pieces of 1 KiB, contiguous in the packed image.
   //      The cursor (dc, dt) walks the slices in step order.
@@ -193,15 +217,25 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
   }
 
   // ---- prologue: window chunk 0, slices 0 .. 2
-  x_issue(0);
-  dma_next(0);
-  if (S > 1) dma_next(1);
-  if (S > 2) dma_next(2);
-  x_write(0);                       // (the compiler waits for the window loads here)
-  G16_STAMP();                      // 1: first window converted and written
   int xl_a = 0, xl_b = 0;           // window loads issued in the previous / in this MEM phase (still counted by vmcnt)
-  if (nch > 1) { x_issue(1); xl_b = 1; }
-  g16_vm_wait<NBW, NL>(false, xl_b);   // slices 0 .. 2 have landed
+  if constexpr (XIN) {
+    xi_issue(0);                    // both window buffers are free: chunks 0 and 1 go out at once
+    if (nch > 1) xi_issue(1);
+    dma_next(0);
+    if (S > 1) dma_next(1);
+    if (S > 2) dma_next(2);
+    G16_STAMP();
+    g16_vmcnt<0>();
+  } else {
+    x_issue(0);
+    dma_next(0);
+    if (S > 1) dma_next(1);
+    if (S > 2) dma_next(2);
+    x_write(0);                       // (the compiler waits for the window loads here)
+    G16_STAMP();                      // 1: first window converted and written
+    if (nch > 1) { x_issue(1); xl_b = 1; }
+    g16_vm_wait<NBW, NL>(false, xl_b);   // slices 0 .. 2 have landed
+  }
   G16_STAMP();                      // 2: slices landed
   G16_BARRIER();
   G16_STAMP();                      // 3: prologue barrier
@@ -232,7 +266,12 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
       });
       xl_a = xl_b;
       xl_b = 0;
-      if (wr_step) {
+      if constexpr (XIN) {
+        // the buffer of chunk - 1 is free from this chunk's first tap on (both wave halves have its last fragments in
+        // registers): chunk + 1 is requested into it K steps before its first use.  It is OLDER than the slices the
+        // counted waits of the chunk's last taps wait for (K >= 3), so it has landed by then.
+        if (tap == 0 && chunk >= 1 && chunk + 1 < nch) { xi_issue(chunk + 1); xl_b = 1; }
+      } else if (wr_step) {
         x_write(chunk_n & 1);                               // the other window buffer: last read a chunk ago
         if (chunk + 2 < nch) { x_issue(chunk + 2); xl_b = 1; }
       }
@@ -316,13 +355,33 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
 #pragma unroll
       for (int j = 0; j < NW; ++j) hh[i][j] += g16_as_f32x4(rv[i][j]);
   }
+  // o_img (round 4): the consumer's operand image of the result -- leaky-relu, hi / lo split, its window's plane layout
+  // [chunk][hi | lo][plane][padded time][8 halfs] -- written here, ONCE, instead of being derived from the fp32 tensor
+  // by every consumer block (XIN above).  A lane's four channels are half a 16-byte row unit: 8-byte stores, lanes
+  // q4 = 0 / 1 (2 / 3) fill the two halves of 16 consecutive rows of one plane.  out == NULL: the image is all that is
+  // kept (a ResBlock's intermediate).
+  const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(
+      a.o_img ? a.o_img + (size_t)b * a.oi_bs : reinterpret_cast<uint16_t*>(a.out), 0,
+      a.o_img ? a.Cout * 4 * a.oi_tpad : 0, 0x00020000);
 #pragma unroll
   for (int i = 0; i < MW; ++i)
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
       f32x4 v = hh[i][j];
       if (a.div != 1.f) v /= a.div;
-      __builtin_amdgcn_raw_buffer_store_b128(g16_as_u32x4(v), ro, oo[i][j], 0, 0);
+      if (a.out) __builtin_amdgcn_raw_buffer_store_b128(g16_as_u32x4(v), ro, oo[i][j], 0, 0);
+      if constexpr (TERMS == 3) {
+        if (a.o_img) {
+          const int co = ((cb * MTB + wm * MW + i) << 4) + 4 * (lane >> 4);
+          const int t = t0 + (wn * NW + j) * 16 + (lane & 15);
+          const int unit = ((((co >> 5) * 2) * 4 + ((co & 31) >> 3)) * a.oi_tpad + G16_IMG_PADF + t) * 16 + 2 * (co & 7);
+          f16x4 eh, el;
+          g16_split4(v, a.oi_slope, true, eh, el);
+          const int off = t < a.Nq ? unit : G16_OOR;
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, eh), ri, off, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, el), ri, off, 4 * a.oi_tpad * 16, 0);
+        }
+      }
     }
 #ifdef G16_STAMPS
   G16_STAMP();                                              // stores issued
@@ -344,13 +403,13 @@ extern "C" int vsp_debug_stamps_g16(unsigned long long* host, int max_samples, i
 }
 #endif
 
-template <int MW, int NW, int WM, int WN, int TERMS>
+template <int MW, int NW, int WM, int WN, int TERMS, bool XIN = false>
 static hipError_t launch_g16_tile(const ClConvArgs& a, int B, hipStream_t s) {
   constexpr int BT = 16 * NW * WN, MTB = MW * WM;
   constexpr size_t lds = (size_t)2 * 2 * 4 * (BT + G16_HALO) * 16 + (size_t)4 * MTB * 2048;
   static_assert(lds <= 160 * 1024, "LDS budget");
   static std::atomic<uint64_t> attr_done{0};
-  auto kern = g16_conv<MW, NW, WM, WN, TERMS>;
+  auto kern = g16_conv<MW, NW, WM, WN, TERMS, XIN>;
   if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, attr_done); e != hipSuccess) return e;
   const int nmt = a.phases * a.Cout / 16;
   if (nmt % MTB || a.Cin % 32) return hipErrorInvalidValue;
@@ -493,7 +552,10 @@ static hipError_t launch_g16_ups(const ClConvArgs& a, int B, hipStream_t s) {
 hipError_t launch_g16_conv(const ClConvArgs& a, int B, hipStream_t s) {
   if ((a.K - 1) * a.dil > G16_HALO || a.K < 1 || a.Nq <= 0 || B <= 0 || a.Cout % 16 || a.Cin % 32 || a.phases < 1 ||
       (a.x_ts & 3) || (a.x_bs & 3) || (reinterpret_cast<uintptr_t>(a.x) & 15) || (a.o_ts & 3) || (a.o_bs & 3) ||
-      (reinterpret_cast<uintptr_t>(a.out) & 15))
+      (reinterpret_cast<uintptr_t>(a.out) & 15) || (!a.out && !a.o_img) || (!a.x && !a.x_img))
+    return hipErrorInvalidValue;
+  if ((a.x_img || a.o_img) && (a.terms != 3 || a.phases != 1)) return hipErrorInvalidValue;
+  if (a.o_img && (a.oi_tpad < cl_img_tpad(a.T_store) || (a.oi_bs & 7) || (reinterpret_cast<uintptr_t>(a.o_img) & 15)))
     return hipErrorInvalidValue;
   const int rows = a.phases * a.Cout;
   // the short up-convs (kernel 4 at stride 4 or 2): streaming kernel (no residual / accumulate operands there)
@@ -524,6 +586,13 @@ hipError_t launch_g16_conv(const ClConvArgs& a, int B, hipStream_t s) {
   int want = 128;
   if (force) want = force;
   else if (col_tiles * (rows / 128 > 0 ? rows / 128 : 1) < fill) want = col_tiles * (rows / 64 > 0 ? rows / 64 : 1) < fill ? 32 : 64;
+  if (a.x_img) {                                                                        // input = operand image (LDS-DMA windows)
+    if (a.K < 3 || a.phases != 1 || a.pad > CL_IMG_PADF || a.xi_tpad < cl_img_tpad(a.T_in) || (a.xi_bs & 7)) return hipErrorInvalidValue;
+    if (rows % 128 == 0 && want >= 128) return launch_g16_tile<4, 4, 2, 4, 3, true>(a, B, s);
+    if (rows % 64 == 0 && want >= 64) return launch_g16_tile<4, 2, 1, 8, 3, true>(a, B, s);
+    if (rows % 32 == 0) return launch_g16_tile<2, 2, 1, 8, 3, true>(a, B, s);
+    return hipErrorInvalidValue;
+  }
   if (rows % 128 == 0 && want >= 128) return launch_g16_tile<4, 4, 2, 4, 3>(a, B, s);   // 128 rows x 256 columns, one block per CU
   if (rows % 64 == 0 && want >= 64) return launch_g16_tile<4, 2, 1, 8, 3>(a, B, s);     //  64 rows x 256 columns
   if (rows % 32 == 0) return launch_g16_tile<2, 2, 1, 8, 3>(a, B, s);                   //  32 rows x 256 columns

@@ -80,7 +80,19 @@ struct ClConvArgs {
   int acc_prev; float div;
   int phases, ups_p, T_store;               // polyphase transposed conv: row n = phases*q + ph - ups_p
   int terms;                                // 3 = fp32-accurate split product (default), 1 = plain f16 operands
+  // Operand images (round 4; terms == 3, phases == 1): layout [chunk32][hi | lo][plane][cl_img_tpad(T)][8 halfs] per
+  // utterance, CL_IMG_PADF zero rows in front of time 0 and CL_IMG_PADB behind time T - 1 (launch_cl_img_zero_pads).
+  //   x_img: read the input from a producer-written image instead of x (K >= 3; in_act / in_slope are then the
+  //          PRODUCER's business); o_img: also (out != NULL) or only (out == NULL) write leaky_relu(result, oi_slope)
+  //          as the next convolution's image.
+  const uint16_t* x_img; long xi_bs; int xi_tpad;   // batch stride in halfs, padded rows per plane
+  uint16_t* o_img; long oi_bs; int oi_tpad; float oi_slope;
 };
+constexpr int CL_IMG_PADF = 64, CL_IMG_PADB = 320;
+inline int cl_img_tpad(int T) { return T + CL_IMG_PADF + CL_IMG_PADB; }
+inline size_t cl_img_halfs(int C, int T) { return (size_t)C * 2 * cl_img_tpad(T); }   // per utterance
+// zero the pad rows of B utterances' images (the data rows are the producer's)
+hipError_t launch_cl_img_zero_pads(uint16_t* img, int B, int C, int T, hipStream_t s);
 
 // Fused ResBlock1 conv pair on channels-last activations (gen16.hip):
 //   out = x + conv2(lrelu(conv1(lrelu(x), dil) + b1), 1) + b2  [+ out] [/ div];  x != out.

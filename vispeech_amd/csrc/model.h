@@ -113,6 +113,7 @@ struct vsp_ctx {
   float* arena = nullptr;
   bool arena_owned = false;
   bool ready = false;
+  bool t_img = true;              // ResBlock intermediates of the per-convolution stages as operand images (VSP_TIMG=0: fp32)
   int64_t noise_first = 0;        // stream index of element 0 of a library-drawn noise tensor (vsp_set_noise_offset)
   bool adopted_pending = false;   // an adopted arena whose header has not been checked yet (vsp_commit_adopted_weights)
   int gen_mode = 1;  // 0: f32 MFMA channel-major generator, 1: split-f16 (fp32-accurate) channels-last generator,
