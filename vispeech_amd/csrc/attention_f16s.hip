@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(64 * NWV * KS) attn_relpos_f16s(const float* _
                                                             const _Float16* __restrict__ Vp, const float* __restrict__ emb_k,
                                                             const float* __restrict__ emb_v,
                                                             const int64_t* __restrict__ lengths, float* __restrict__ out,
-                                                            long o_bs, long o_cs, int H, int T, int w) {
+                                                            long o_bs, long o_cs, int H, int T, int w, int n_heads, int n_utt) {
   constexpr int NC = DK / 32, ND = DK / 16;
   constexpr int QB = 16 * NQ * NWV;                  // queries per block
   constexpr int KTILE = 2 * NC * 2 * 1024;           // bytes of a 32-key K tile (2 key tiles x NC chunks x hi/lo)
@@ -168,8 +168,24 @@ __global__ void __launch_bounds__(64 * NWV * KS) attn_relpos_f16s(const float* _
   const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave = wave_all % NWV, ks = wave_all / NWV;     // query group; which of the KS key-tile streams
   const int lane = tid & 63, l15 = lane & 15, q4 = lane >> 4;
-  const int b = blockIdx.z, hd = blockIdx.y, i0 = blockIdx.x * QB;
-  const int n_heads = gridDim.y;
+  // XCD-aware block numbering: consecutive workgroup ids go to consecutive XCDs (eight L2s), so with a plain 3-D grid
+  // the query blocks of one (utterance, head) -- which all stream the same K / V images -- sat on different L2s (counter
+  // table of round 3: L2 hit rate 0.11, waves 53 % in s_waitcnt).  With at least eight (utterance, head) groups, group g
+  // lives on XCD g % 8 and its query blocks take consecutive slots there: the first block of a group pulls a tile into
+  // that L2, the others hit.  Fewer groups (one long utterance): the plain order, every XCD works on every group.
+  const int nqb = (T + QB - 1) / QB;                  // query blocks per group
+  const int ngroups = n_heads * n_utt;
+  int qb, grp;
+  if (ngroups >= 8) {
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    qb = slot % nqb;
+    grp = (slot / nqb) * 8 + xcd;
+    if (grp >= ngroups) return;                       // (padding of the group count to a multiple of eight)
+  } else {
+    qb = blockIdx.x % nqb;
+    grp = blockIdx.x / nqb;
+  }
+  const int b = grp / n_heads, hd = grp - b * n_heads, i0 = qb * QB;
   const int nrel = 2 * w + 1;
   const int len = lengths ? (int)lengths[b] : T;
   const size_t tpad = (size_t)(T + 63) / 64 * 64;
@@ -434,9 +450,12 @@ static void launch_attn_f16s(const float* qkv, long qkv_bs, long qkv_cs, const _
                              const _Float16* Vp, const float* emb_k, const float* emb_v, const int64_t* lengths, float* out,
                              long o_bs, long o_cs, int B, int H, int n_heads, int T, int window, hipStream_t s) {
   constexpr int QB = 16 * NQ * NWV;
-  dim3 grid((T + QB - 1) / QB, n_heads, B);
+  const int nqb = (T + QB - 1) / QB, ngroups = n_heads * B;
+  // (one-dimensional grid, the kernel maps it: groups padded to a multiple of eight when they are spread over the XCDs)
+  const long nblocks = (long)nqb * (ngroups >= 8 ? (ngroups + 7) / 8 * 8 : ngroups);
+  dim3 grid((unsigned)nblocks);
   hipLaunchKernelGGL((attn_relpos_f16s<DK, NWV, NQ, KS>), grid, dim3(64 * NWV * KS), 0, s, qkv, qkv_bs, qkv_cs, Qp, Kp, Vp, emb_k,
-                     emb_v, lengths, out, o_bs, o_cs, H, T, window);
+                     emb_v, lengths, out, o_bs, o_cs, H, T, window, n_heads, B);
 }
 
 // workspace: 3 * attn_pack_bytes(B, n_heads, dk, T), 256-byte aligned
