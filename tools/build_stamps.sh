@@ -1,9 +1,14 @@
 #!/bin/bash
-# Build the in-kernel-stamp variant of libvispeech_hip.so (-DG16_STAMPS, see gen16.hip) into build/g16stamps/.
+# Diagnostic builds with in-kernel wall-clock stamps (s_memrealtime), next to the product library:
+#   build/g16stamps/  -DG16_STAMPS  (gen16.hip: g16_pair phase stamps, tools/stamps_pair.py)
+#   build/rwstamps/   -DRW_STAMPS   (gen16_rw.hip: per-wave phase timeline of the persistent pair kernel, tools/stamps_rw.py)
 set -e
 cd "$(dirname "$0")/../vispeech_amd/csrc"
-mkdir -p ../../build/g16stamps
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DG16_STAMPS -shared conv_mfma.hip cl_misc.hip gen16.hip attention.hip attention_f16s.hip misc.hip api.hip -x hip weights.cpp -o ../../build/g16stamps/libvispeech_hip.so 2>&1 | grep -E "error" || true
-# ... and of the frame-rate latency kernels (-DFR_STAMPS, see conv_mfma.hip; tools/stamps_frame.py) into build/frstamps/.
-mkdir -p ../../build/frstamps
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DFR_STAMPS -shared conv_mfma.hip cl_misc.hip gen16.hip attention.hip attention_f16s.hip misc.hip api.hip -x hip weights.cpp -o ../../build/frstamps/libvispeech_hip.so 2>&1 | grep -E "error" || true
+SRCS="conv_mfma.hip cl_misc.hip gen16.hip gen16_rw.hip attention.hip attention_f16s.hip misc.hip api.hip -x hip weights.cpp"
+for V in "g16stamps G16_STAMPS" "rwstamps RW_STAMPS"; do
+  set -- $V
+  mkdir -p ../../build/$1
+  # shellcheck disable=SC2086
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -D$2 -shared $SRCS -o ../../build/$1/libvispeech_hip.so 2>&1 | grep -E "error" || true
+  ls -la ../../build/$1/libvispeech_hip.so
+done

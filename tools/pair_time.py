@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One fused-pair launch sequence at the C3 size of the 32-channel stage (64 x 250368 rows), for rocprofv3 --kernel-trace:
-usage: r04_pair_time.py <C> <K> <dil,dil,..> [B] [T]"""
+usage: pair_time.py <C> <K> <dil,dil,..> [B] [T]"""
 import ctypes as C
 import sys
 

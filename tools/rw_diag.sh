@@ -1,13 +1,13 @@
 #!/bin/bash
-# timing-only ablations of g16_rw (VSP_RW_DIAG bits) at the C3 size of the 32-channel stage; usage: r04_rw_diag.sh <diag..>
+# timing-only ablations of g16_rw (VSP_RW_DIAG bits) at the C3 size of the 32-channel stage; usage: rw_diag.sh <diag..>
 set -u
 : "${GRAFT_REPO_ROOT:?run through gpurun}"
 cd /tmp && export TMPDIR=/tmp
-R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out/r04_rw_diag"; mkdir -p "$O"
+R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out/rw_diag"; mkdir -p "$O"
 for D in "$@"; do
   for K in 7 11; do
     rm -rf "$O/t"; export VSP_RW_DIAG="$D"
-    rocprofv3 --kernel-trace --output-format csv -d "$O/t" -o t -- python3 "$R/tools/r04_pair_time.py" 32 $K 1,3,5 > /dev/null 2>> "$O/err.txt"
+    rocprofv3 --kernel-trace --output-format csv -d "$O/t" -o t -- python3 "$R/tools/pair_time.py" 32 $K 1,3,5 > /dev/null 2>> "$O/err.txt"
     python3 - "$O/t" "$D" "$K" <<'PY' | tee -a "$O/table.txt"
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]

@@ -10,7 +10,7 @@ for i in $(seq 1 "$N"); do
     if [ "$D" != "product" ]; then export VSP_LIB_PATH="$R/build/$D/libvispeech_hip.so"; else unset VSP_LIB_PATH; fi
     for K in ${KS:-7 11}; do
       rm -rf "$O/t"
-      rocprofv3 --kernel-trace --output-format csv -d "$O/t" -o t -- python3 "$R/tools/r04_pair_time.py" ${CH:-32} $K 1,3,5 > /dev/null 2>> "$O/err.txt"
+      rocprofv3 --kernel-trace --output-format csv -d "$O/t" -o t -- python3 "$R/tools/pair_time.py" ${CH:-32} $K 1,3,5 > /dev/null 2>> "$O/err.txt"
       python3 - "$O/t" "$D" "$K" <<'PY' | tee -a "$O/table.txt"
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
