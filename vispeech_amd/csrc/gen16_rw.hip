@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(512) g16_rw(ClPairArgs a, int total_tiles) {
 }
 
 bool g16_rw_supported(int C, int K, int dil, int terms) {
-  return C == 32 && (K == 7 || K == 11) && dil >= 1 && (K - 1) * dil <= RW_MAXHALO && terms == 3;
+  return C == 32 && (K == 3 || K == 7 || K == 11) && dil >= 1 && (K - 1) * dil <= RW_MAXHALO && terms == 3;
 }
 
 template <int K, bool ACC>
@@ -438,6 +438,7 @@ hipError_t launch_g16_rw(const ClPairArgs& a0, int B, hipStream_t s) {
       (reinterpret_cast<uintptr_t>(a.x) & 15) || (reinterpret_cast<uintptr_t>(a.out) & 15) || a.x == a.out ||
       (size_t)a.T * 128 >= (size_t)1 << 31)
     return hipErrorInvalidValue;
+  if (a.K == 3) return a.acc_prev ? launch_g16_rw_k<3, true>(a, B, s) : launch_g16_rw_k<3, false>(a, B, s);
   if (a.acc_prev) return a.K == 7 ? launch_g16_rw_k<7, true>(a, B, s) : launch_g16_rw_k<11, true>(a, B, s);
   return a.K == 7 ? launch_g16_rw_k<7, false>(a, B, s) : launch_g16_rw_k<11, false>(a, B, s);
 }
