@@ -87,6 +87,7 @@ struct ClConvArgs {
   //          as the next convolution's image.
   const uint16_t* x_img; long xi_bs; int xi_tpad;   // batch stride in halfs, padded rows per plane
   uint16_t* o_img; long oi_bs; int oi_tpad; float oi_slope;
+  int pt_gx, pt_gy, pt_total;               // set by the persistent launcher: time tiles, row groups, tiles in all
 };
 constexpr int CL_IMG_PADF = 64, CL_IMG_PADB = 320;
 inline int cl_img_tpad(int T) { return T + CL_IMG_PADF + CL_IMG_PADB; }
@@ -125,6 +126,10 @@ struct ClChainArgs {
 bool g16_chain_supported(int C, int K, const int* dil, int np);
 hipError_t launch_g16_chain(const ClChainArgs& a, int B, hipStream_t s);
 hipError_t launch_g16_conv(const ClConvArgs& a, int B, hipStream_t s);
+// image-input convolutions on the 128-row tile as persistent blocks pipelined across tiles (gen16_pipe.hip): measured
+// no faster than one block per tile, so launch_g16_conv routes there only under VSP_G16_PIPE=1 (bit-identical)
+bool g16_pipe_supported(const ClConvArgs& a);
+hipError_t launch_g16_pipe(const ClConvArgs& a, int B, hipStream_t s);
 bool g16_pair_supported(int C, int K, int dil);
 hipError_t launch_g16_pair(const ClPairArgs& a, int B, hipStream_t s);
 // the same pair with the weights held in registers by persistent blocks (gen16_rw.hip: 32 channels, kernel 7 / 11);
