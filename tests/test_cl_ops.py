@@ -180,8 +180,9 @@ def test_cl_resblock_operand_images_on_a_full_grid(lib, c, k, dils, b, t):
 
 def test_pipelined_tile_kernel_is_bit_identical_in_a_child_process():
     """g16_convp (gen16_pipe.hip: persistent blocks, weight ring / window stream / ping-pong continuing across tile
-    boundaries) is a measured negative result kept behind VSP_G16_PIPE=1; the switch is read once per process, so a child
-    process runs the full-grid cases with it and compares with the default path bit for bit (and with torch's fp64)."""
+    boundaries) serves the tiles of few steps by default; VSP_G16_PIPE=1 forces it everywhere, =0 nowhere.  The switch is
+    read once per process, so child processes run the full-grid cases both ways and the outputs must agree bit for bit
+    (and with torch's fp64)."""
     import os
     import subprocess
     import sys
@@ -200,9 +201,8 @@ def test_pipelined_tile_kernel_is_bit_identical_in_a_child_process():
     import tempfile
     with tempfile.TemporaryDirectory() as d:
         got = {}
-        for tag, env in (("pipe", {"VSP_G16_PIPE": "1"}), ("plain", {})):
+        for tag, env in (("pipe", {"VSP_G16_PIPE": "1"}), ("plain", {"VSP_G16_PIPE": "0"})):
             e = dict(os.environ, **env)
-            e.pop("VSP_G16_PIPE", None) if not env else None
             p = subprocess.run([sys.executable, "-c", code, os.path.join(d, tag)], env=e, capture_output=True, text=True, timeout=600)
             assert p.returncode == 0 and "child ok" in p.stdout, p.stderr[-2000:]
             got[tag] = {f: np.load(os.path.join(d, f)) for f in sorted(os.listdir(d)) if f.startswith(tag + "_")}

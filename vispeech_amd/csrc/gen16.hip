@@ -589,7 +589,7 @@ hipError_t launch_g16_conv(const ClConvArgs& a, int B, hipStream_t s) {
   if (a.x_img) {                                                                        // input = operand image (LDS-DMA windows)
     if (a.K < 3 || a.phases != 1 || a.pad > CL_IMG_PADF || a.xi_tpad < cl_img_tpad(a.T_in) || (a.xi_bs & 7)) return hipErrorInvalidValue;
     if (rows % 128 == 0 && want >= 128) {
-      if (g16_pipe_supported(a)) return launch_g16_pipe(a, B, s);                        // (VSP_G16_PIPE=1: persistent, pipelined across tiles)
+      if (g16_pipe_supported(a)) return launch_g16_pipe(a, B, s);                        // persistent, pipelined across tiles
       return launch_g16_tile<4, 4, 2, 4, 3, true>(a, B, s);
     }
     if (rows % 64 == 0 && want >= 64) return launch_g16_tile<4, 2, 1, 8, 3, true>(a, B, s);

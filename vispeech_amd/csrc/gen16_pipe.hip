@@ -1,6 +1,6 @@
 // g16_convp: the 128 / 256-channel ResBlock convolutions as PERSISTENT blocks whose pipeline runs ACROSS tiles (round 4).
-// A MEASURED NEGATIVE RESULT, kept switchable (VSP_G16_PIPE=1; bit-identical; tests/test_cl_ops.py runs it in a child
-// process): profiles/r04_g16_conv_persistent_blocks.txt.
+// Used for the tiles of few steps (g16_pipe_supported below); VSP_G16_PIPE=0 / 1 = never / always, all bit-identical
+// (tests/test_cl_ops.py runs the forced form in a child process).  Measurements: profiles/r04_g16_conv_persistent_blocks.txt.
 //
 // The idea.  g16_conv (gen16.hip) reaches 86 % of the power-limited MFMA rate inside a tile's step loop, but a tile's time is
 // steps x 0.94-1.0 us PLUS 12-17 us (128 channels) / 19 us (256 channels) -- fitted over K = 3 / 7 / 11 --, and with one
@@ -14,16 +14,17 @@
 //   * the ping-pong of the two wave halves never stops: a tile's epilogue (cross accumulators folded, residual, stores,
 //     operand image of the result) sits at the top of the MEM phase of the NEXT tile's first step, so the first half's
 //     epilogue runs beside the second half's last MFMA phase and vice versa; accumulators restart at the bias.
-// What was measured (same box, per launch, second convolutions of the pairs at the C3 size): first version 12-20 % SLOWER
+// What it took (same box, per launch, second convolutions of the pairs at the C3 size).  First version: 12-20 % SLOWER
 // than one block per tile (1.78 -> 2.03 ms at 128 channels K = 11): the MEM phase of a step is the critical path of the
-// ping-pong (0.48 us against 0.46 us of MFMAs), and run-time wait counts, three stream cursors and 28 spilled scalar
-// registers read back by v_readlane sat in it.  With immediates for the steady-state waits and the epilogue's parameters
-// re-read from the kernel-argument segment (no scalar spills): +0.4 ms per step over the 18 launches, i.e. equal within
-// 2 %; starting block k (k mod 8) / 8 of a tile late (de-synchronised epilogues): worse.  The constant is NOT set-up,
-// first-request latency or tear-down -- all of which this kernel removes --: it is the two wave halves' epilogues (16 tiles
-// per wave: fold, addresses, residual round trip, 16-48 stores), which stay exposed one after the other whatever the
-// schedule, because `vmcnt` retires a wave's loads, stores and LDS-DMA in ONE order: every wait for a slice requested after
-// the stores is also a wait for the stores.
+// ping-pong (0.48 us against 0.46 us of MFMAs), and run-time wait counts, three carried stream cursors and 28 spilled
+// scalar registers read back by v_readlane sat in it.  Immediates for the steady-state waits, the epilogue's parameters
+// re-read from the kernel-argument segment, request cursors derived from the compute cursor: equal within 2 %.  Then the
+// SECOND wave half's epilogue moved to the end of its last MFMA phase -- the phase in which the first half runs its own
+// at the top of the next tile's first MEM phase -- so the two epilogues overlap instead of following each other: K = 3
+// -12 % (128 channels) / -5 % (256), K = 7 -2 % / +1 %, K = 11 -1 % / +6 %.  Starting blocks staggered (de-synchronised
+// epilogues, across or within XCDs): worse.  What still sits at a tile boundary is one epilogue's length (16 tiles per wave:
+// fold, addresses, residual round trip, 16-48 stores), and `vmcnt` retires a wave's loads, stores and LDS-DMA in ONE order:
+// every wait for a slice requested after the stores is also a wait for the stores.
 // Same arithmetic per output as g16_conv (chunk-major, tap-minor, HH / CROSS / CROSS, bias in the accumulator): results
 // are bit-identical.
 //
@@ -95,13 +96,17 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_convp(ClConvArgs a) {
     if (++t.cb == gy) { t.cb = 0; if (++t.bx == gx) { t.bx = 0; ++t.b; } }
     return t;
   };
+  auto tile_prev = [&](G16Tile t) {
+    if (--t.cb < 0) { t.cb = gy - 1; if (--t.bx < 0) { t.bx = gx - 1; --t.b; } }
+    return t;
+  };
   G16Tile tc = tile_at(id_lo);                 // tile being multiplied
-  G16Tile tw = tc;                             // tile of the next window chunk to request
-  int cb_r = tc.cb;                            // row group of the next weight slice to request
+  // (the request cursors are DERIVED from the compute cursor -- the window stream runs one chunk ahead, the slice stream
+  // three steps -- instead of being carried: every scalar carried around the step loop beyond ~90 is spilled to vector
+  // lanes and read back in the MEM phase, the critical path of the ping-pong)
 
   // ---- window chunks by LDS-DMA (as g16_conv<.., XIN>): wave w copies (image w / 4, plane w % 4)
-  int cw = 0;                                  // chunk (within tile tw) of the next window request
-  auto xi_issue_next = [&]() {
+  auto xi_issue = [&](G16Tile tw, int cw) {
     const int img = wave >> 2, plane = wave & 3;
     const size_t row0 = (((size_t)cw * 2 + img) * 4 + plane) * a.xi_tpad + (size_t)(G16_IMG_PADF + tw.bx * BT - a.pad);
     const uint4* gp0 = reinterpret_cast<const uint4*>(a.x_img + (size_t)tw.b * a.xi_bs) + row0 + lane;
@@ -110,12 +115,12 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_convp(ClConvArgs a) {
     for (int u = 0; u < NL; ++u)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp0 + u * 64),
                                        (__attribute__((address_space(3))) void*)(lp0 + u * 1024), 16, 0, 0);
-    if (++cw == nch) { cw = 0; tw = tile_next(tw); }
   };
-  // ---- weight slices by LDS-DMA: one endless sequence over the block's tiles
+  // ---- weight slices by LDS-DMA: one endless sequence over the block's tiles; (dc, dt) = the next slice to request,
+  //      cb_r = the row group of its tile
   const uint4* Wg = reinterpret_cast<const uint4*>(a.wh);
   int dc = 0, dt = 0;
-  auto dma_next = [&](int slot) {
+  auto dma_next = [&](int slot, int cb_r) {
     const size_t src = (((size_t)dc * K + dt) * nmt + (size_t)cb_r * MTB) * 128;   // uint4 units (2 KiB per m-tile)
 #pragma unroll
     for (int u = 0; u < NBW; ++u) {
@@ -127,10 +132,7 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_convp(ClConvArgs a) {
                                          (__attribute__((address_space(3))) void*)lp, 16, 0, 0);
       }
     }
-    if (++dt == K) {
-      dt = 0;
-      if (++dc == nch) { dc = 0; if (++cb_r == gy) cb_r = 0; }
-    }
+    if (++dt == K) { dt = 0; if (++dc == nch) dc = 0; }
   };
   const bool has_pieces = NBLK % NWV == 0 || wave < NBLK;
   const int my_pieces = has_pieces ? NBW : 0;   // (NBLK < NWV: at most one piece per wave, NBW == 1)
@@ -234,23 +236,26 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_convp(ClConvArgs a) {
 
   // ---- prologue: the stream's first two window chunks (both buffers are free), slices 0 .. 2
   acc_init(tc.cb);
-  xi_issue_next();
-  if (total_chunks > 1) xi_issue_next();
-  dma_next(0);
-  if (total_steps > 1) dma_next(1);
-  if (total_steps > 2) dma_next(2);
+  xi_issue(tc, 0);
+  if (total_chunks > 1) xi_issue(tc, 1);      // (nch >= 2: the stream's second chunk is this tile's)
+  dma_next(0, tc.cb);                         // (S >= 6: the first three slices are this tile's)
+  dma_next(1, tc.cb);
+  dma_next(2, tc.cb);
   g16_vmcnt<0>();
   G16_BARRIER();
   if (wave >= NWV / 2) G16_BARRIER();            // the second wave half runs one phase behind the first
 
   int xl_a = 0, xl_b = 0;                        // window groups requested in the previous / in this MEM phase
   int chunk = 0, tap = 0, slot = 0, cgi = 0;     // of the current step; cgi = chunk index in the block's stream
-  int since_epi = 2;                             // steps since an epilogue at the top of a MEM phase (>= 2: none pending)
-  G16Tile tprev = tc;
+  int since_epi = 2;                             // MEM phases since this wave's last epilogue (>= 2: none pending)
+  const bool first_half = wave < NWV / 2;
   for (int gs = 0; gs < total_steps; ++gs) {
     // ================= MEM phase of step gs =================
-    if (chunk == 0 && tap == 0 && gs > 0) {      // the previous tile is complete: its epilogue, then a fresh accumulator
-      epilogue(tprev);
+    // The previous tile is complete: its epilogue, then a fresh accumulator.  FIRST wave half: here, at the top of the next
+    // tile's first MEM phase (beside the second half's last MFMA phase).  SECOND half: at the END of its last MFMA phase
+    // (below) -- the same phase --, so the two halves' epilogues overlap instead of following each other.
+    if (first_half && chunk == 0 && tap == 0 && gs > 0) {
+      epilogue(tile_prev(tc));
       acc_init(tc.cb);
       since_epi = 0;
     }
@@ -271,8 +276,12 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_convp(ClConvArgs a) {
       xl_b = 0;
       // the buffer of the stream's previous chunk is free from this chunk's first tap on: the next chunk -- maybe the next
       // tile's first -- is requested into it K steps before its first use
-      if (tap == 0 && cgi >= 1 && cgi + 1 < total_chunks) { xi_issue_next(); xl_b = 1; }
-      if (gs + 3 < total_steps) dma_next(slot == 0 ? NS - 1 : slot - 1);   // slice gs + 3 into the slot slice gs - 1 left
+      if (tap == 0 && cgi >= 1 && cgi + 1 < total_chunks) {
+        if (chunk + 1 < nch) xi_issue(tc, chunk + 1); else xi_issue(tile_next(tc), 0);
+        xl_b = 1;
+      }
+      if (gs + 3 < total_steps)                             // slice gs + 3 into the slot slice gs - 1 left
+        dma_next(slot == 0 ? NS - 1 : slot - 1, chunk * K + tap + 3 >= S ? (tc.cb + 1 == gy ? 0 : tc.cb + 1) : tc.cb);
       if (gs + 1 < total_steps) {
         // my pieces of slice gs + 1 (requested in step gs - 2) have landed: younger are slices gs + 2, gs + 3, the window
         // groups of this and the previous phase and, in a tile's first two steps, the previous tile's epilogue stores
@@ -302,18 +311,25 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_convp(ClConvArgs a) {
     });
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
-    G16_BARRIER();
     ++since_epi;
     slot = slot == NS - 1 ? 0 : slot + 1;
     if (++tap == K) {
       tap = 0;
       ++cgi;
-      if (++chunk == nch) { chunk = 0; tprev = tc; tc = tile_next(tc); }
+      if (++chunk == nch) {
+        chunk = 0; tc = tile_next(tc);
+        if (!first_half && gs + 1 < total_steps) {          // second half: the finished tile's epilogue in this very phase
+          epilogue(tile_prev(tc));
+          acc_init(tc.cb);
+          since_epi = 0;
+        }
+      }
     }
+    G16_BARRIER();
   }
   // (the first wave half has executed one barrier fewer: it goes straight to the last tile's epilogue, which overlaps the
   // second half's last MFMA phase; a wave that has ended no longer takes part in the barrier)
-  epilogue(tprev);
+  epilogue(tile_prev(tc));
 }
 
 template <int MW, int NW, int WM, int WN>
@@ -341,11 +357,17 @@ static hipError_t launch_g16_pipe_tile(ClConvArgs a, int B, hipStream_t s) {
   return hipGetLastError();
 }
 
+// Where it pays (same box, per launch, second convolutions of the pairs at the C3 size; profiles/r04_g16_conv_persistent_blocks.txt):
+// tiles of few steps, where the boundary is a large share -- 128 channels K = 3 -12 %, K = 7 -2 %, 256 channels K = 3 -5 %;
+// at 44-88 steps per tile (K = 11, 256 channels K = 7) the leaner step of the one-block-per-tile kernel wins by 1-6 %.
+// Default: tiles of at most 28 steps.  VSP_G16_PIPE=0: never, =1: always (both bit-identical to the default).
 bool g16_pipe_supported(const ClConvArgs& a) {
-  // OFF by default: measured no faster than one block per tile (header comment); VSP_G16_PIPE=1 switches it on
-  static const bool on = []() { const char* e = getenv("VSP_G16_PIPE"); return e && atoi(e) != 0; }();
-  return on && a.x_img && a.terms == 3 && a.phases == 1 && a.K >= 3 && a.pad <= CL_IMG_PADF && a.Cin % 64 == 0 &&
-         a.Cout % 128 == 0 && (a.K - 1) * a.dil <= G16_HALO;
+  static const int mode = []() { const char* e = getenv("VSP_G16_PIPE"); return e ? atoi(e) : -1; }();
+  if (mode == 0) return false;
+  if (!(a.x_img && a.terms == 3 && a.phases == 1 && a.K >= 3 && a.pad <= CL_IMG_PADF && a.Cin % 64 == 0 &&
+        a.Cout % 128 == 0 && (a.K - 1) * a.dil <= G16_HALO))
+    return false;
+  return mode == 1 || (a.Cin / 32) * a.K <= 28;
 }
 
 // (the 128-row x 256-column tile: what launch_g16_conv picks when the launch fills the chip)

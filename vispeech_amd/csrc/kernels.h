@@ -126,8 +126,8 @@ struct ClChainArgs {
 bool g16_chain_supported(int C, int K, const int* dil, int np);
 hipError_t launch_g16_chain(const ClChainArgs& a, int B, hipStream_t s);
 hipError_t launch_g16_conv(const ClConvArgs& a, int B, hipStream_t s);
-// image-input convolutions on the 128-row tile as persistent blocks pipelined across tiles (gen16_pipe.hip): measured
-// no faster than one block per tile, so launch_g16_conv routes there only under VSP_G16_PIPE=1 (bit-identical)
+// image-input convolutions on the 128-row tile as persistent blocks pipelined across tiles (gen16_pipe.hip):
+// launch_g16_conv routes tiles of at most 28 steps there (VSP_G16_PIPE=0: never, =1: always -- bit-identical)
 bool g16_pipe_supported(const ClConvArgs& a);
 hipError_t launch_g16_pipe(const ClConvArgs& a, int B, hipStream_t s);
 bool g16_pair_supported(int C, int K, int dil);
