@@ -305,7 +305,9 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     G16_STAMP();                                            // 6 + 4 s: MFMAs issued
-    G16_BARRIER();
+    // (the second half skips the barrier behind its LAST MFMA phase: nothing in the LDS is read after it, and waiting there
+    // would hold its epilogue until the first half's waves have ENDED -- the two epilogues would follow each other)
+    if (s + 1 < S || wave < NWV / 2) G16_BARRIER();
     G16_STAMP();                                            // 7 + 4 s: barrier
     chunk = chunk_n;
     tap = tap_n;
