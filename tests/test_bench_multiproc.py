@@ -44,7 +44,7 @@ def test_two_rank_bench_self_launches_on_one_gpu():
     assert d["config"]["valid_samples_per_step"] == 512 * int(b["frame_lengths"].sum())      # the ONE batch, counted once
     assert d["config"]["padded_frames"] == int(b["frame_lengths"].max())                     # global padding (G6)
     assert "cpu_baseline" not in d                            # timed on rank 0 at N = 1 only
-    assert d["roofline"]["launches"] == 57 and d["roofline"]["attention"]["launches"] == 8
+    assert d["roofline"]["launches"] == 51 and d["roofline"]["attention"]["launches"] == 8
     assert 0 < d["rank_ms_per_step"]["min"] <= d["rank_ms_per_step"]["max"] <= d["ms_per_step"] * 1.001
     g = d["gather"]
     assert g["bytes_into_rank0_per_step"] == 4 * 512 * d["config"]["padded_frames"] * 3 and 0.0 <= g["share_of_step"] < 1.0
@@ -76,4 +76,4 @@ def test_rccl_path_runs_on_hardware_with_one_rank():
     assert d["n_gpus"] == 1 and d["n_ranks_seen"] == 1 and "nccl" in d["collectives"]
     assert d["value"] > 0 and d["config"]["utterances_per_gpu"] == 4 and d["config"]["global_batch"] == 4
     assert "per GPU" in d["config"]["workload"]               # (one GPU: the headline line reads as before)
-    assert d["roofline"]["launches"] == 57
+    assert d["roofline"]["launches"] == 51

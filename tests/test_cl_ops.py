@@ -109,8 +109,8 @@ def test_cl_resblock_three_implementations(lib, c, k, dils, b, t):
     darr = (C.c_int * len(dils))(*dils)
     outs = []
     for mode in (0, 1, 2):
-        if mode == 1 and c > 64:
-            outs.append(None)                       # (the pair kernel covers 32 / 64 channels)
+        if mode == 1 and c > 64 and not (c == 128 and k in (3, 7)):
+            outs.append(None)                       # (pair kernels: 32 / 64 channels; 128 channels at kernel 3: g16_pp)
             continue
         out = torch.full((b, t, c), float("nan"), device="cuda")
         rc = lib.vsp_cl_resblock(stream, b, t, c, k, len(dils), darr, P(xd), host_ptrs(ws), host_ptrs(bs), mode, 3, P(out))
@@ -178,6 +178,19 @@ def test_cl_resblock_operand_images_on_a_full_grid(lib, c, k, dils, b, t):
         assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
 
 
+@pytest.mark.parametrize("k,dils,b,t", [(3, (1, 3, 5), 4, 16000), (3, (5, 1), 2, 40011), (3, (8,), 1, 70001),
+                                        (7, (1, 3, 5), 3, 16000), (7, (5,), 1, 50001)])
+def test_cl_resblock_pair_on_the_ping_pong_tile_on_a_full_grid(lib, k, dils, b, t):
+    """g16_pp (gen16_pp.hip): the kernel-3 / kernel-7 conv pair of the 128-channel stage as ONE launch on g16_conv's ping-pong
+    tile -- all four window chunks resident, conv1's tile handed over through the dead window.  Grids that fill the chip,
+    time axes that are no multiple of the 190 / 186 output columns of a block: against torch's fp64 convolution and bit for bit
+    against the two-launch path (mode 0) and the whole-ResBlock chain (mode 2, <= 3 pairs with a short halo)."""
+    x, ws, bs, outs = _full_grid_resblock(lib, 128, k, dils, b, t, (0, 1, 2))
+    assert rel_err(outs[1].cpu().numpy(), torch_resblock(x, ws, bs, dils, k)) <= TOL
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o), float((outs[0] - o).abs().max())
+
+
 def test_pipelined_tile_kernel_is_bit_identical_in_a_child_process():
     """g16_convp (gen16_pipe.hip: persistent blocks, weight ring / window stream / ping-pong continuing across tile
     boundaries) serves the tiles of few steps by default; VSP_G16_PIPE=1 forces it everywhere, =0 nowhere.  The switch is
@@ -227,8 +240,8 @@ def test_cl_ops_refuse_what_they_cannot_do(lib):
     assert lib.vsp_cl_resblock(stream, 1, 8, 32, 3, 1, d, P(x), host_ptrs([w, w]), host_ptrs([w, w]), 2, 3, P(x)) == -1          # in place
     x128 = torch.zeros(1, 8, 128, device="cuda")
     o128 = torch.zeros(1, 8, 128, device="cuda")
-    w128 = np.zeros((128, 128, 3), dtype=np.float32)
-    assert lib.vsp_cl_resblock(stream, 1, 8, 128, 3, 1, d, P(x128), host_ptrs([w128, w128]), host_ptrs([w128, w128]), 1, 3, P(o128)) == -7   # pairs: 32 / 64 channels
+    w128 = np.zeros((128, 128, 11), dtype=np.float32)
+    assert lib.vsp_cl_resblock(stream, 1, 8, 128, 11, 1, d, P(x128), host_ptrs([w128, w128]), host_ptrs([w128, w128]), 1, 3, P(o128)) == -7   # pairs: 32 / 64 channels, 128 at kernel 3 / 7
     assert lib.vsp_cl_resblock(stream, 1, 0, 32, 3, 1, d, P(x), host_ptrs([w, w]), host_ptrs([w, w]), 2, 3, P(out)) == 0         # empty
 
 

@@ -11,7 +11,7 @@ rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if 'conv_post' in r['Kernel_Name']]
 seg = rows[idx[-2] + 1: idx[-1] + 1]
-gen = [r for r in seg if any(k in r['Kernel_Name'] for k in ('g16_conv', 'g16_pair', 'g16_chain', 'g16_ups', 'g16_rw'))]
+gen = [r for r in seg if any(k in r['Kernel_Name'] for k in ('g16_conv', 'g16_pair', 'g16_chain', 'g16_ups', 'g16_rw', 'g16_pp'))]
 c0 = 512
 rates = [8, 8, 4, 2]; uk = [16, 16, 4, 4]; ks = [3, 7, 11]
 specs = []
@@ -36,6 +36,9 @@ while si < len(specs) and gi < len(gen):
     if 'g16_chain' in gen[gi]['Kernel_Name'] and kind == 'pair':
         merged.append((name[:-2] + 'ch', 'chain', co, ci, K, N, Nout, res, 3))
         si += 3
+    elif 'g16_pp' in gen[gi]['Kernel_Name'] and kind == 'conv' and name.endswith('a'):
+        merged.append((name[:-1], 'pair', co, ci, K, N, Nout, 1, 1))     # one launch for the pair's two convolutions
+        si += 2
     else:
         merged.append((name, kind, co, ci, K, N, Nout, res, 1))
         si += 1

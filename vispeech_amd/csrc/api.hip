@@ -502,7 +502,9 @@ void run_generator_cl(Run& r, int B, int T, T3 z, const int64_t* in_lengths, con
         const ResBlockW& rb = m.rbs[i * nk + j];
         const int nd = (int)rb.dil.size();
         bool fuse = r.ctx->fuse_pairs;
-        for (int d = 0; d < nd; ++d) fuse = fuse && g16_pair_supported(ch, rb.k, rb.dil[d]);
+        const int terms = r.ctx->gen_mode == 2 ? 1 : 3;
+        for (int d = 0; d < nd; ++d)
+          fuse = fuse && (g16_pair_supported(ch, rb.k, rb.dil[d]) || g16_pp_supported(ch, rb.k, rb.dil[d], terms));
         const int kbit = rb.k <= 3 ? 1 : rb.k <= 7 ? 2 : 4;
         if (fuse && (r.ctx->chain_mask & kbit) && ch <= r.ctx->chain_ch && nd <= 3 &&
             g16_chain_supported(ch, rb.k, rb.dil.data(), nd)) {
@@ -1663,7 +1665,7 @@ int vsp_cl_resblock(void* stream, int B, int T, int C, int K, int n_pairs, const
   if (C <= 0 || C % 32 || K < 1 || !(K & 1) || (size_t)T * C * 4 >= (size_t)1 << 31) return VSP_ERR_UNSUPPORTED;
   for (int p = 0; p < n_pairs; ++p) {
     if (dilations[p] < 1 || (K - 1) * dilations[p] > 64) return VSP_ERR_UNSUPPORTED;
-    if (mode == 1 && !g16_pair_supported(C, K, dilations[p])) return VSP_ERR_UNSUPPORTED;
+    if (mode == 1 && !g16_pair_supported(C, K, dilations[p]) && !g16_pp_supported(C, K, dilations[p], terms)) return VSP_ERR_UNSUPPORTED;
     if (!w_host[2 * p] || !w_host[2 * p + 1]) return VSP_ERR_ARG;
   }
   if (mode == 2 && (n_pairs > 3 || !g16_chain_supported(C, K, dilations, n_pairs))) return VSP_ERR_UNSUPPORTED;

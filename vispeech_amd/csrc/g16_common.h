@@ -138,6 +138,17 @@ __device__ __forceinline__ void g16_split4(const f32x4 v, float slope, bool act,
     el[2 * k] = xl.x; el[2 * k + 1] = xl.y;
   }
 }
+// v / div the way the reference divides (IEEE division: x / 3 is not x * (1 / 3)), behind a REAL branch.  hipcc
+// if-converts `if (div != 1.f) v /= div` into an unconditional division plus a select -- 12 vector instructions and a
+// quarter-rate v_rcp per value, 64 values per lane of the 128-row tile: ~800 instructions in the epilogue of EVERY tile,
+// although only the last convolution of a stage divides.  The asm statement in the block cannot be speculated, and the
+// operand passes through it, so the division stays behind the (uniform, scalar) branch.
+__device__ __forceinline__ void g16_div(f32x4& v, float div) {
+  if (div != 1.f) {
+    asm volatile("" : "+v"(v));
+    v /= div;
+  }
+}
 __device__ __forceinline__ f32x4 g16_as_f32x4(const u32x4 v) {
   return f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
 }

@@ -370,7 +370,7 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
       f32x4 v = hh[i][j];
-      if (a.div != 1.f) v /= a.div;
+      g16_div(v, a.div);
       if (a.out) __builtin_amdgcn_raw_buffer_store_b128(g16_as_u32x4(v), ro, oo[i][j], 0, 0);
       if constexpr (TERMS == 3) {
         if (a.o_img) {
@@ -897,7 +897,7 @@ __global__ void __launch_bounds__(64 * NWV, 4) g16_pair(ClPairArgs a) {
       if constexpr (EARLY_RES) v += g16_as_f32x4(res_early[i][j]);
       else v += g16_as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
       if (a.acc_prev) v += g16_as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(ro, off, 0, 0));
-      if (a.div != 1.f) v /= a.div;
+      g16_div(v, a.div);
       __builtin_amdgcn_raw_buffer_store_b128(g16_as_u32x4(v), ro, off, 0, 0);
     }
 #ifdef G16_STAMPS
@@ -936,6 +936,7 @@ bool g16_pair_supported(int C, int K, int dil) {
 }
 
 hipError_t launch_g16_pair(const ClPairArgs& a, int B, hipStream_t s) {
+  if (a.C == 128) return launch_g16_pp(a, B, s);       // the ping-pong tile pair (gen16_pp.hip)
   if (!g16_pair_supported(a.C, a.K, a.dil) || a.T <= 0 || B <= 0 || (a.x_bs & 3) || (a.o_bs & 3) ||
       (reinterpret_cast<uintptr_t>(a.x) & 15) || (reinterpret_cast<uintptr_t>(a.out) & 15) || a.x == a.out)
     return hipErrorInvalidValue;
@@ -1232,7 +1233,7 @@ __global__ void __launch_bounds__(64 * NWV, 2) g16_chain(ClChainArgs a) {
       f32x4 v = result(i, j);
       v += xr[i][j];
       if (a.acc_prev) v += g16_as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(ro, off, 0, 0));
-      if (a.div != 1.f) v /= a.div;
+      g16_div(v, a.div);
       if ((G16_DIAG & 8) == 0) __builtin_amdgcn_raw_buffer_store_b128(g16_as_u32x4(v), ro, off, 0, 0);
     }
 #ifdef G16_STAMPS

@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_convp(ClConvArgs a) {
 #pragma unroll
       for (int j = 0; j < NW; ++j) {
         f32x4 v = hh[i][j];
-        if (a.div != 1.f) v /= a.div;
+        g16_div(v, a.div);
         if (a.out) __builtin_amdgcn_raw_buffer_store_b128(g16_as_u32x4(v), ro, oo[i][j], 0, 0);
         if (a.o_img) {
           const int co = ((t.cb * MTB + wm * MW + i) << 4) + 4 * (lane_e >> 4);

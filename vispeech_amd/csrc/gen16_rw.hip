@@ -392,7 +392,7 @@ __global__ void __launch_bounds__(512) g16_rw(ClPairArgs a, int total_tiles) {
           v0 += g16_as_f32x4(res[s][0]);
           v1 += g16_as_f32x4(res[s][1]);
           if constexpr (ACC) { v0 += g16_as_f32x4(prv[s][0]); v1 += g16_as_f32x4(prv[s][1]); }
-          if (a.div != 1.f) { v0 /= a.div; v1 /= a.div; }
+          g16_div(v0, a.div); g16_div(v1, a.div);
           __builtin_amdgcn_raw_buffer_store_b128(g16_as_u32x4(v0), ro, off, 0, 0);
           __builtin_amdgcn_raw_buffer_store_b128(g16_as_u32x4(v1), ro, off, 64, 0);
           RW_STAMP(6 + g);

@@ -136,6 +136,9 @@ hipError_t launch_g16_pair(const ClPairArgs& a, int B, hipStream_t s);
 // launch_g16_pair routes there unless VSP_PAIR=ring asks for the LDS-ring kernel (second implementation, bit-identical)
 bool g16_rw_supported(int C, int K, int dil, int terms);
 hipError_t launch_g16_rw(const ClPairArgs& a, int B, hipStream_t s);
+// the pair of the 128-channel stage on the ping-pong tile, kernel 3 (gen16_pp.hip); VSP_PP=0: two launches (bit-identical)
+bool g16_pp_supported(int C, int K, int dil, int terms);
+hipError_t launch_g16_pp(const ClPairArgs& a, int B, hipStream_t s);
 size_t packed_g16_halfs(int rows, int Cin, int K);
 void pack_g16_weights(uint16_t* dst, int rows, int Cin, int K, const float* dense /* [rows][Cin][K] */);
 // mel[b][m][t] = log(max(sum_{f in [lo[m], hi[m])} basis[m][f] * spec[b][f][t], 1e-5))  (reference mel_processing.py:16-22, 73-82)
