@@ -179,6 +179,17 @@ __device__ __forceinline__ void conv_epi_load(const ConvArgs& a, ConvEpi<MT, NT>
   }
 }
 
+// v / div as the reference divides (IEEE), behind a REAL scalar branch: hipcc if-converts `if (div != 1.f) v /= div` into
+// an unconditional division + select (12 vector instructions and a quarter-rate v_rcp per value: 200 per 32 x 32 tile in
+// every epilogue, although only the f32 generator's last ResBlock convolution divides).  The operand passes through an asm
+// statement inside the block, which cannot be speculated.
+__device__ __forceinline__ void conv_div(float& v, float div) {
+  if (div != 1.f) {
+    asm volatile("" : "+v"(v));
+    v /= div;
+  }
+}
+
 template <int MT, int NT>
 __device__ __forceinline__ void conv_epi_store(const ConvArgs& a, f32x16 (&acc)[MT][NT], const ConvEpi<MT, NT>& e, int mtile0,
                                                int n_mtiles, int t0, int wn, int l31, int h, int b, int len) {
@@ -252,7 +263,7 @@ __device__ __forceinline__ void conv_epi_store(const ConvArgs& a, f32x16 (&acc)[
         if (a.alpha != 1.f) v *= a.alpha;
         if (has_res) v += __uint_as_float(e.rv[mt][nt][r]);
         if (a.acc_prev) v += __uint_as_float(e.pv[mt][nt][r]);
-        if (a.div != 1.f) v /= a.div;
+        conv_div(v, a.div);
         if (a.mask_post && !valid) v = 0.f;
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro, (qin && row < a.M) ? (row * (int)a.o_cs + q) * 4 : CONV_OOR, 0, 0);
       }
@@ -730,7 +741,7 @@ __global__ void __launch_bounds__(64 * WM * WN, F16S ? 2 : 1) conv1d_f32_mfma(Co
         if (a.alpha != 1.f) v *= a.alpha;
         if (resb) v += rv[r];
         if (a.acc_prev) v += pv[r];
-        if (a.div != 1.f) v /= a.div;
+        conv_div(v, a.div);
         if (a.mask_post && !valid) v = 0.f;
         outb[oidx[r]] = v;
       }
