@@ -179,10 +179,12 @@ def test_cl_resblock_operand_images_on_a_full_grid(lib, c, k, dils, b, t):
 
 
 @pytest.mark.parametrize("k,dils,b,t", [(3, (1, 3, 5), 4, 16000), (3, (5, 1), 2, 40011), (3, (8,), 1, 70001),
-                                        (7, (1, 3, 5), 3, 16000), (7, (5,), 1, 50001)])
+                                        (7, (1, 3, 5), 3, 16000), (7, (5,), 1, 50001), (3, (3,), 8, 30000), (7, (1,), 7, 29000)])
 def test_cl_resblock_pair_on_the_ping_pong_tile_on_a_full_grid(lib, k, dils, b, t):
     """g16_pp (gen16_pp.hip): the kernel-3 / kernel-7 conv pair of the 128-channel stage as ONE launch on g16_conv's ping-pong
-    tile -- all four window chunks resident, conv1's tile handed over through the dead window.  Grids that fill the chip,
+    tile -- all four window chunks resident, conv1's tile handed over through the dead window -- by PERSISTENT blocks that
+    walk runs of tiles (the next tile's first window chunk staged during conv2, the weight ring streaming on; runs of one to
+    five tiles here, crossing utterance boundaries).  Grids that fill the chip,
     time axes that are no multiple of the 190 / 186 output columns of a block: against torch's fp64 convolution and bit for bit
     against the two-launch path (mode 0) and the whole-ResBlock chain (mode 2, <= 3 pairs with a short halo)."""
     x, ws, bs, outs = _full_grid_resblock(lib, 128, k, dils, b, t, (0, 1, 2))

@@ -90,6 +90,9 @@ __global__ void __launch_bounds__(512) g16_pp(ClPairArgs a) {
 #endif
   PP_STAMP(1);
 
+  // timing-only diagnostics (VSP_PP_DIAG, results WRONG): 1 no residual loads, 2 no stores, 4 no window loads, 8 no
+  // hand-over work, 16 no MFMAs, 32 no window conversion / writes, 64 every weight slice from the same bytes, 128 no slice waits
+  const int diag = a.terms >> 8;
   const int K = a.K, p2 = (K - 1) >> 1, p1 = a.dil * p2;
   const int R2 = BT - (K - 1);                  // output columns per block
   const int t0 = tile * R2;                     // first output column
@@ -113,11 +116,12 @@ __global__ void __launch_bounds__(512) g16_pp(ClPairArgs a) {
 #pragma unroll
     for (int u = 0; u < NL; ++u) {
       const bool in = (u + 1) * RPS <= BT || row_s + u * RPS < xrows;
-      sv[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, in ? st_voff + (base + u * RPS * C * 4) : G16_OOR, 0, 0);
+      sv[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, (in && !(diag & 4)) ? st_voff + (base + u * RPS * C * 4) : G16_OOR, 0, 0);
     }
   };
   auto x_write = [&](int chunk) {
     char* dst0 = Xw + chunk * XBUF + st_loff;
+    if (diag & 32) return;
     g16_for<NL>([&](auto U) {
       constexpr int u = decltype(U)::value;
       f16x4 eh, el;
@@ -133,7 +137,7 @@ __global__ void __launch_bounds__(512) g16_pp(ClPairArgs a) {
   int dv = 0, dc = 0, dt = 0;
   auto dma_next = [&](int slot) {
     const uint4* Wg = reinterpret_cast<const uint4*>(dv ? a.w2h : a.w1h);
-    const size_t src = ((size_t)dc * K + dt) * MTB * 128;      // uint4 units (2 KiB per m-tile)
+    const size_t src = (diag & 64) ? 0 : ((size_t)dc * K + dt) * MTB * 128;      // uint4 units (2 KiB per m-tile)
 #pragma unroll
     for (int u = 0; u < NBW; ++u) {
       const int p = u * NWV + wave;
@@ -218,7 +222,7 @@ __global__ void __launch_bounds__(512) g16_pp(ClPairArgs a) {
         }
         // my pieces of slice gs + 1 have landed: issued after them are the previous phase's window loads, slice gs + 2
         // and this phase's window loads
-        if (gs + 1 < S) {
+        if (gs + 1 < S && !(diag & 128)) {
           if (gs + 2 < S) g16_vm_wait<NBW, NL>(true, xl_a + xl_b);
           else g16_vm_wait<0, NL>(false, xl_a + xl_b);
         }
@@ -230,6 +234,7 @@ __global__ void __launch_bounds__(512) g16_pp(ClPairArgs a) {
       // ================= MFMA phase =================
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
+      if (!(diag & 16))
       g16_for<NW>([&](auto J) {
         constexpr int j = decltype(J)::value;
         g16_for<MW>([&](auto I) {
@@ -260,6 +265,7 @@ __global__ void __launch_bounds__(512) g16_pp(ClPairArgs a) {
   // Channel 64 wm + 16 i + 4 q4 + e sits in chunk 2 wm + (i >> 1), plane 2 (i & 1) + (q4 >> 1), byte 8 (q4 & 1) + 2 e of
   // the row's 16.  Image row j = time t0 - p2 + j; rows outside the utterance are conv2's zero padding.
   PP_STAMP(20);
+  if (!(diag & 8))
 #pragma unroll
   for (int j = 0; j < NW; ++j) {
     const int row = wn * NW * 16 + 16 * j + l15;
@@ -303,7 +309,7 @@ __global__ void __launch_bounds__(512) g16_pp(ClPairArgs a) {
 #pragma unroll
   for (int i = 0; i < MW; ++i)
 #pragma unroll
-    for (int j = 0; j < NW; ++j) rv[i][j] = __builtin_amdgcn_raw_buffer_load_b128(rx, oo[i][j], 0, 0);
+    for (int j = 0; j < NW; ++j) rv[i][j] = __builtin_amdgcn_raw_buffer_load_b128(rx, (diag & 1) ? G16_OOR : oo[i][j], 0, 0);
 #ifdef PP_STAMPS
   PP_STAMP(31);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -332,7 +338,7 @@ __global__ void __launch_bounds__(512) g16_pp(ClPairArgs a) {
     for (int j = 0; j < NW; ++j) {
       f32x4 v = hh[i][j];
       g16_div(v, a.div);
-      __builtin_amdgcn_raw_buffer_store_b128(g16_as_u32x4(v), ro, oo[i][j], 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(g16_as_u32x4(v), ro, (diag & 2) ? G16_OOR : oo[i][j], 0, 0);
     }
 #ifdef PP_STAMPS
   PP_STAMP(33);
@@ -355,6 +361,8 @@ static hipError_t launch_g16_pp_tile(ClPairArgs a, int B, hipStream_t s) {
   a.tiles = (a.T + R2 - 1) / R2;
   const long n = (long)a.tiles * B;
   if (n <= 0 || n > 0x7fffffffL) return hipErrorInvalidValue;
+  static const int diag = []() { const char* e = getenv("VSP_PP_DIAG"); return e ? atoi(e) : 0; }();
+  a.terms |= diag << 8;
   hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(512), lds, s, a);
   return hipGetLastError();
 }
