@@ -133,18 +133,21 @@ __global__ void __launch_bounds__(512) g16_pp(ClPairArgs a) {
     });
   };
 
-  // ---- weight slices by LDS-DMA: global slice index gs in [0, S): conv = gs / S1, then chunk-major, one tap per slice
-  int dv = 0, dc = 0, dt = 0;
+  // ---- weight slices by LDS-DMA: global slice index gs in [0, S): conv = gs / S1, then chunk-major, one tap per slice:
+  //      the slices of a convolution are consecutive 16 KiB runs of its packed image -- a running pointer (the scalar work
+  //      of a MEM phase is on the ping-pong's critical path: no multiplies, no selects)
+  const char* dsrc = reinterpret_cast<const char*>(a.w1h);      // (uniform; + d_lane: this lane's 16 bytes of the wave's piece)
+  const unsigned d_lane = (wave * 64 + lane) * 16;
+  int dleft = S1;                               // slices left in the convolution being requested
   auto dma_next = [&](int slot) {
-    const uint4* Wg = reinterpret_cast<const uint4*>(dv ? a.w2h : a.w1h);
-    const size_t src = (diag & 64) ? 0 : ((size_t)dc * K + dt) * MTB * 128;      // uint4 units (2 KiB per m-tile)
-#pragma unroll
-    for (int u = 0; u < NBW; ++u) {
-      const int p = u * NWV + wave;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wg + src + (size_t)p * 64 + lane),
-                                       (__attribute__((address_space(3))) void*)(Rg + slot * SLOT + p * 1024), 16, 0, 0);
-    }
-    if (++dt == K) { dt = 0; if (++dc == NCH) { dc = 0; ++dv; } }
+    char* const dst = Rg + slot * SLOT + wave * 1024;
+    const char* const src = (diag & 64) ? reinterpret_cast<const char*>(a.w1h) : dsrc;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + d_lane),
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + NWV * 1024 + d_lane),
+                                     (__attribute__((address_space(3))) void*)(dst + NWV * 1024), 16, 0, 0);
+    dsrc += SLOT;
+    if (--dleft == 0) { dleft = S1; dsrc = reinterpret_cast<const char*>(a.w2h); }
   };
 
   // ---- fragments: asm reads with immediate offsets off two per-step base addresses
@@ -195,17 +198,14 @@ __global__ void __launch_bounds__(512) g16_pp(ClPairArgs a) {
       const bool last_tap = tap == K - 1;
       // ================= MEM phase =================
       {
+        // (order: the B reads, the slice request and the staging decision, the A reads -- a wave issues one ds_read_b128
+        // per ~19 clocks, the scalar work of the request fits between them instead of following them)
         const unsigned b_cur = xb_lane + chunk * XBUF + tap * rowstep * 16;
         const unsigned a_cur = wa_lane + slot * SLOT;
         g16_for<NW>([&](auto J) {
           constexpr int j = decltype(J)::value;
           Bh[j] = g16_lds_read<j * 256>(b_cur);
           Bl[j] = g16_lds_read<j * 256 + XIMG>(b_cur);
-        });
-        g16_for<MW>([&](auto I) {
-          constexpr int i = decltype(I)::value;
-          Ah[i] = g16_lds_read<i * 2048>(a_cur);
-          Al[i] = g16_lds_read<i * 2048 + 1024>(a_cur);
         });
         xl_a = xl_b;
         xl_b = 0;
@@ -220,6 +220,11 @@ __global__ void __launch_bounds__(512) g16_pp(ClPairArgs a) {
         } else if (gs + 2 < S) {
           dma_next(slot == 0 ? NS - 1 : slot - 1);
         }
+        g16_for<MW>([&](auto I) {
+          constexpr int i = decltype(I)::value;
+          Ah[i] = g16_lds_read<i * 2048>(a_cur);
+          Al[i] = g16_lds_read<i * 2048 + 1024>(a_cur);
+        });
         // my pieces of slice gs + 1 have landed: issued after them are the previous phase's window loads, slice gs + 2
         // and this phase's window loads
         if (gs + 1 < S && !(diag & 128)) {
