@@ -178,22 +178,23 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
                                        (__attribute__((address_space(3))) void*)(lp0 + u * 1024), 16, 0, 0);
   };
   // ---- weight slices by LDS-DMA: slice (chunk, tap) = NBLK pieces of 1 KiB, contiguous in the packed image.
-  //      The cursor (dc, dt) walks the slices in step order.
-  const uint4* Wg = reinterpret_cast<const uint4*>(a.wh);
-  int dc = 0, dt = 0;
+  //      Slices are requested in step order (chunk-major, tap-minor).
+  //      (consecutive slices of a block are nmt * 2 KiB apart: a running pointer -- the scalar work of a MEM phase is on
+  //      the ping-pong's critical path)
+  const char* dsrc = reinterpret_cast<const char*>(a.wh) + (size_t)cb * MTB * 2048;   // uniform
+  const unsigned d_lane = (wave * 64 + lane) * 16;
+  const int dstep = (G16_DIAG & 32) ? 0 : nmt * 2048;
   auto dma_next = [&](int slot) {
-    const size_t src = (G16_DIAG & 32) ? 0 : (((size_t)dc * K + dt) * nmt + (size_t)cb * MTB) * 128;   // uint4 units (2 KiB per m-tile)
 #pragma unroll
     for (int u = 0; u < NBW; ++u) {
       const int blk = u * NWV + wave;
       if ((NBLK % NWV == 0 || blk < NBLK) && (G16_DIAG & 2) == 0) {
-        const uint4* gp = Wg + src + (size_t)blk * 64 + lane;
         char* lp = Rg + slot * SLOT + blk * 1024;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dsrc + u * NWV * 1024 + d_lane),
                                          (__attribute__((address_space(3))) void*)lp, 16, 0, 0);
       }
     }
-    if (++dt == K) { dt = 0; ++dc; }
+    dsrc += dstep;
   };
   // (a wave that copies no piece of a slice -- NBLK < NWV -- has nothing of its own to wait for there)
   const bool has_pieces = NBLK % NWV == 0 || wave < NBLK;
@@ -254,15 +255,12 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
     {
       const unsigned b_cur = xb_lane + (chunk & 1) * XBUF + tap * a.dil * 16;
       const unsigned a_cur = wa_lane + slot * SLOT;
+      // (order: the B reads, the requests, the A reads -- a wave issues one ds_read_b128 per ~19 clocks
+      // (tools/micro/lds_read_bw.hip): the scalar work of the requests fits between them instead of following them)
       g16_for<NW>([&](auto J) {
         constexpr int j = decltype(J)::value;
         Bh[j] = g16_lds_read<j * 256>(b_cur);
         if constexpr (TERMS == 3) Bl[j] = g16_lds_read<j * 256 + XIMG>(b_cur);
-      });
-      g16_for<MW>([&](auto I) {
-        constexpr int i = decltype(I)::value;
-        Ah[i] = g16_lds_read<i * 2048>(a_cur);
-        if constexpr (TERMS == 3) Al[i] = g16_lds_read<i * 2048 + 1024>(a_cur);
       });
       xl_a = xl_b;
       xl_b = 0;
@@ -276,6 +274,11 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
         if (chunk + 2 < nch) { x_issue(chunk + 2); xl_b = 1; }
       }
       if (s + 3 < S) dma_next(slot == 0 ? NS - 1 : slot - 1);   // slice s + 3 into the slot slice s - 1 left
+      g16_for<MW>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        Ah[i] = g16_lds_read<i * 2048>(a_cur);
+        if constexpr (TERMS == 3) Al[i] = g16_lds_read<i * 2048 + 1024>(a_cur);
+      });
       // my pieces of slice s + 1 have landed: issued after them are slices s + 2, s + 3 and the window loads of this
       // and the previous MEM phase
       if (s + 1 < S) {
