@@ -412,7 +412,7 @@ def main():
                     {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": f_hbm})
             roof.update({
                 "traffic": None,
-                "kernel": "generator convolutions (g16_conv; g16_pair / g16_chain: fused ResBlock pairs / whole ResBlocks on the 64/32-channel stages; g16_ups: their streaming up-convs), rank 0",
+                "kernel": "generator convolutions (g16_conv / g16_convp: one launch per convolution; g16_pp / g16_pair / g16_rw: fused ResBlock conv pairs of the 128- / 64- / 32-channel stages; g16_chain: whole k3 ResBlocks of the 32-channel stage; g16_ups: the streaming up-convs; conv_post), rank 0",
                 "launches": g["launches"], "kernel_ms_per_step": g["ms"], "avg_launch_ms": g["ms"] / max(g["launches"], 1),
                 "alg_tflops": tfl, "alg_frac": tfl / peak, "alg_flops_per_launch": g["flops"] / max(g["launches"], 1),
                 "alg_gbs": gbs, "alg_bytes_per_launch": g["bytes"] / max(g["launches"], 1),

@@ -403,9 +403,11 @@ def test_reduced_precision_mode_is_opt_in_and_gated(dims, weights, golden_dir, m
 
 
 @pytest.mark.parametrize("env", [{"VSP_FUSE_PAIRS": "0"}, {"VSP_CHAIN": "0"}, {"VSP_CHAIN": "7"}, {"VSP_PAIR": "ring"},
-                                 {"VSP_TIMG": "0"}, {"VSP_FUSE_PAIRS": "0", "VSP_TIMG": "0"}],
+                                 {"VSP_TIMG": "0"}, {"VSP_FUSE_PAIRS": "0", "VSP_TIMG": "0"}, {"VSP_PP": "0"},
+                                 {"VSP_PP": "0", "VSP_TIMG": "0"}],
                          ids=["two_launches", "pair_launches", "chains_for_every_kernel_size", "ring_pair_kernel",
-                              "fp32_intermediates", "two_launches_fp32_intermediates"])
+                              "fp32_intermediates", "two_launches_fp32_intermediates", "no_128_channel_pair_kernel",
+                              "no_128_channel_pair_kernel_fp32_intermediates"])
 def test_fused_resblock_paths_are_bit_identical(net, dims, weights, monkeypatch, env):
     """The ResBlocks of the 32/64-channel stages run fused (gen16.hip): by default a whole ResBlock of the
     32-channel stage is ONE launch (g16_chain: the running x in registers, every intermediate in LDS, the chain's halo
@@ -413,8 +415,9 @@ def test_fused_resblock_paths_are_bit_identical(net, dims, weights, monkeypatch,
     everywhere, VSP_FUSE_PAIRS=0 one g16_conv launch per convolution, VSP_CHAIN=7 chains for k3, k7 and k11.  Round 4:
     the k7 / k11 pairs of the 32-channel stage run on the persistent register-weights kernel (g16_rw; VSP_PAIR=ring = the
     LDS-ring pair kernel), and the per-convolution stages hand a pair's intermediate over as an operand image
-    (VSP_TIMG=0 = as an fp32 tensor).  Same split products, same accumulation order => identical bits, for tiles that
-    start/end anywhere in the utterance."""
+    (VSP_TIMG=0 = as an fp32 tensor); the k3 / k7 pairs of the 128-channel stage are one launch on the ping-pong tile
+    (g16_pp; VSP_PP=0 = two launches).  Every switch is read when a context is created.  Same split products, same
+    accumulation order => identical bits, for tiles that start/end anywhere in the utterance."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     from vispeech_amd import config as vcfg

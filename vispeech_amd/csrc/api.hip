@@ -182,6 +182,7 @@ struct Run {
     a.slope = 0.1f;                                    // modules.LRELU_SLOPE (reference modules.py:17)
     a.acc_prev = acc_prev ? 1 : 0; a.div = div;
     a.terms = ctx->gen_mode == 2 ? 1 : 3;
+    a.ring = ctx->pair_ring ? 1 : 0;
     const bool prof = prof_begin(VSP_PROF_GENERATOR);
     chk(launch_g16_pair(a, B, s), "g16_pair");
     if (prof) {
@@ -504,7 +505,7 @@ void run_generator_cl(Run& r, int B, int T, T3 z, const int64_t* in_lengths, con
         bool fuse = r.ctx->fuse_pairs;
         const int terms = r.ctx->gen_mode == 2 ? 1 : 3;
         for (int d = 0; d < nd; ++d)
-          fuse = fuse && (g16_pair_supported(ch, rb.k, rb.dil[d]) || g16_pp_supported(ch, rb.k, rb.dil[d], terms));
+          fuse = fuse && (g16_pair_supported(ch, rb.k, rb.dil[d]) || (r.ctx->pp_pairs && g16_pp_supported(ch, rb.k, rb.dil[d], terms)));
         const int kbit = rb.k <= 3 ? 1 : rb.k <= 7 ? 2 : 4;
         if (fuse && (r.ctx->chain_mask & kbit) && ch <= r.ctx->chain_ch && nd <= 3 &&
             g16_chain_supported(ch, rb.k, rb.dil.data(), nd)) {
@@ -588,6 +589,8 @@ int vsp_create(const vsp_config* cfg, int device, vsp_ctx** out) {
   }
   if (const char* e = getenv("VSP_FUSE_PAIRS")) ctx->fuse_pairs = atoi(e) != 0;
   if (const char* e = getenv("VSP_TIMG")) ctx->t_img = atoi(e) != 0;   // 0: ResBlock intermediates as fp32 tensors (second implementation)
+  if (const char* e = getenv("VSP_PP")) ctx->pp_pairs = atoi(e) != 0;  // 0: the 128-channel stage's k3 / k7 pairs as two launches
+  if (const char* e = getenv("VSP_PAIR")) ctx->pair_ring = !strcmp(e, "ring");
   if (const char* e = getenv("VSP_CHAIN")) ctx->chain_mask = atoi(e);
 #ifdef VSP_EXPERIMENTS
   if (const char* e = getenv("VSP_ATT_KSPLIT")) ctx->att_ksplit = atoi(e);
@@ -1705,6 +1708,7 @@ int vsp_cl_resblock(void* stream, int B, int T, int C, int K, int n_pairs, const
         a.w1h = static_cast<const uint16_t*>(w[2 * p].p); a.w2h = static_cast<const uint16_t*>(w[2 * p + 1].p);
         a.b1 = static_cast<const float*>(bias[2 * p].p); a.b2 = static_cast<const float*>(bias[2 * p + 1].p);
         a.C = C; a.K = K; a.dil = dilations[p]; a.T = T; a.slope = 0.1f; a.acc_prev = 0; a.div = 1.f; a.terms = terms;
+        if (const char* ev = getenv("VSP_PAIR")) a.ring = !strcmp(ev, "ring");     // (read per call: the test API has no context)
         e = launch_g16_pair(a, B, s);
       } else {
         // one launch per convolution; the intermediate as an operand image where the kernels take one (terms 3, K >= 3):

@@ -951,10 +951,9 @@ hipError_t launch_g16_pair(const ClPairArgs& a, int B, hipStream_t s) {
 #else
   constexpr int nwv = 8;
 #endif
-  // round 4: weights in registers, persistent blocks (gen16_rw.hip) where that kernel exists; VSP_PAIR=ring keeps the
+  // round 4: weights in registers, persistent blocks (gen16_rw.hip) where that kernel exists; ClPairArgs::ring (VSP_PAIR=ring) keeps the
   // LDS-ring kernel below (the second implementation under test: bit-identical)
-  static const bool rw_on = []() { const char* e = getenv("VSP_PAIR"); return !(e && !strcmp(e, "ring")); }();
-  if (rw_on && g16_rw_supported(a.C, a.K, a.dil, a.terms)) return launch_g16_rw(a, B, s);
+  if (!a.ring && g16_rw_supported(a.C, a.K, a.dil, a.terms)) return launch_g16_rw(a, B, s);
   if (a.terms == 1)
     return a.C == 32 ? launch_g16_pair_tile<1, 2, 1, 8>(a, B, s) : launch_g16_pair_tile<2, 1, 1, 8>(a, B, s);
   // round 3: TWO ring slots of twice the taps (32 channels: 4 taps = 16 KB, 64 channels: 2 taps = 16 KB; 72 KB of LDS

@@ -372,11 +372,10 @@ static hipError_t launch_g16_pp_tile(ClPairArgs a, int B, hipStream_t s) {
   return hipGetLastError();
 }
 
-// 128 channels, fp32-accurate products, kernel 3 (window halo <= 16 rows) -- the pairs that are HBM-side bound as two
-// launches.  VSP_PP=0 keeps the two-launch path (second implementation, bit-identical).
+// 128 channels, fp32-accurate products, kernel 3 (window halo <= 16 rows) and kernel 7 (<= 32 rows).  The generator
+// asks per context (VSP_PP=0: the two-launch path, second implementation, bit-identical).
 bool g16_pp_supported(int C, int K, int dil, int terms) {
-  static const bool on = []() { const char* e = getenv("VSP_PP"); return !(e && !strcmp(e, "0")); }();
-  return on && C == 128 && terms == 3 && dil >= 1 && ((K == 3 && 2 * dil <= 16) || (K == 7 && 6 * dil <= 32));
+  return C == 128 && terms == 3 && dil >= 1 && ((K == 3 && 2 * dil <= 16) || (K == 7 && 6 * dil <= 32));
 }
 
 hipError_t launch_g16_pp(const ClPairArgs& a, int B, hipStream_t s) {

@@ -106,6 +106,7 @@ struct ClPairArgs {
   float slope;                              // leaky-relu slope applied to both convs' inputs
   int acc_prev; float div;                  // out = (result + out) / div
   int terms;                                // 3 = split product, 1 = plain f16 operands
+  int ring;                                 // 1: the LDS-ring pair kernel (g16_pair) even where the register-weights one exists
   int tiles;                                // set by the launcher: tiles per utterance
   int xrows;                                // set by the launcher: staged window rows
 };
@@ -133,10 +134,10 @@ hipError_t launch_g16_pipe(const ClConvArgs& a, int B, hipStream_t s);
 bool g16_pair_supported(int C, int K, int dil);
 hipError_t launch_g16_pair(const ClPairArgs& a, int B, hipStream_t s);
 // the same pair with the weights held in registers by persistent blocks (gen16_rw.hip: 32 channels, kernel 7 / 11);
-// launch_g16_pair routes there unless VSP_PAIR=ring asks for the LDS-ring kernel (second implementation, bit-identical)
+// launch_g16_pair routes there unless ClPairArgs::ring (VSP_PAIR=ring) asks for the LDS-ring kernel (second implementation, bit-identical)
 bool g16_rw_supported(int C, int K, int dil, int terms);
 hipError_t launch_g16_rw(const ClPairArgs& a, int B, hipStream_t s);
-// the pair of the 128-channel stage on the ping-pong tile, kernel 3 (gen16_pp.hip); VSP_PP=0: two launches (bit-identical)
+// the pair of the 128-channel stage on the ping-pong tile, kernel 3 / 7 (gen16_pp.hip); VSP_PP=0 (read per context): two launches (bit-identical)
 bool g16_pp_supported(int C, int K, int dil, int terms);
 hipError_t launch_g16_pp(const ClPairArgs& a, int B, hipStream_t s);
 size_t packed_g16_halfs(int rows, int Cin, int K);
