@@ -148,6 +148,34 @@ def test_cl_resblock_persistent_pair_kernel_long_rows(lib, k, dils, b, t):
     assert rel_err(outs[1].numpy(), torch_resblock(x, ws, bs, dils, k)) <= TOL
 
 
+@pytest.mark.parametrize("dils", [(1, 3, 5), (5, 5, 5), (2, 1, 8)])
+@pytest.mark.parametrize("b,t", [(3, 40000), (1, 190000), (5, 777), (2, 168), (1, 169)])
+def test_cl_resblock_chain_role_pipeline_long_rows(lib, dils, b, t, monkeypatch):
+    """g16_rc (gen16_rc.hip): the whole kernel-3 ResBlock of the 32-channel stage as a role pipeline -- the six
+    convolutions' weights in registers, persistent blocks, two tiles in flight three iterations apart, the running x in
+    the conv2 waves' registers.  Runs of many tiles (crossing utterance boundaries), of one tile and of exactly 168 / 169
+    columns (one tile / one tile + one column): bit for bit against the per-convolution path (mode 0), the pair path
+    (mode 1) and the LDS-ring chain kernel (VSP_CHAIN_RING=1), and against torch's fp64 convolution."""
+    c, k = 32, 3
+    r = np.random.Generator(np.random.PCG64(sum(dils) * 31 + t))
+    x = r.standard_normal((b, t, c)).astype(np.float32)
+    ws = [(r.standard_normal((c, c, k)) / np.sqrt(c * k)).astype(np.float32) for _ in range(2 * len(dils))]
+    bs = [r.standard_normal(c).astype(np.float32) * 0.1 for _ in range(2 * len(dils))]
+    xd = torch.from_numpy(x).cuda()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    darr = (C.c_int * len(dils))(*dils)
+    outs = []
+    for mode, ring in ((0, "0"), (1, "0"), (2, "0"), (2, "1")):
+        monkeypatch.setenv("VSP_CHAIN_RING", ring)
+        out = torch.full((b, t, c), float("nan"), device="cuda")
+        rc = lib.vsp_cl_resblock(stream, b, t, c, k, len(dils), darr, P(xd), host_ptrs(ws), host_ptrs(bs), mode, 3, P(out))
+        assert rc == 0, (mode, ring)
+        outs.append(out.cpu())
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o), float((outs[0] - o).abs().max())
+    assert rel_err(outs[2].numpy(), torch_resblock(x, ws, bs, dils, k)) <= TOL
+
+
 PIPE_CASES = [(128, 3, (1, 5), 4, 16000), (128, 11, (3,), 5, 13000), (256, 7, (5, 1), 3, 11000)]
 
 

@@ -5,7 +5,7 @@
 #   build/ppstamps/   -DPP_STAMPS   (gen16_pp.hip: phase timeline of the 128-channel pair kernel, tools/stamps_pp.py)
 set -e
 cd "$(dirname "$0")/../vispeech_amd/csrc"
-SRCS="conv_mfma.hip cl_misc.hip gen16.hip gen16_rw.hip gen16_pipe.hip gen16_pp.hip attention.hip attention_f16s.hip misc.hip api.hip -x hip weights.cpp"
+SRCS="conv_mfma.hip cl_misc.hip gen16.hip gen16_rw.hip gen16_pipe.hip gen16_pp.hip gen16_rc.hip attention.hip attention_f16s.hip misc.hip api.hip -x hip weights.cpp"
 for V in "g16stamps G16_STAMPS" "rwstamps RW_STAMPS" "ppstamps PP_STAMPS"; do
   set -- $V
   if [ -n "${ONLY:-}" ] && [ "$ONLY" != "$1" ]; then continue; fi

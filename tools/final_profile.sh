@@ -10,7 +10,7 @@ R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out/final"; rm -rf "$O"; mkdir -p "$O"
 # here the fresh numbers are merged into this run's bench line by refresh_profiles.py)
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -o p -- python3 "$R/bench.py" --steps 1 --warmup 1 --profile-steps 0 --no-cpu-baseline > /dev/null 2>> "$O/bench.err" || true
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" -o p -- python3 "$R/bench.py" --steps 1 --warmup 1 --profile-steps 0 --no-cpu-baseline > /dev/null 2>> "$O/bench.err" || true
-python3 "$R/tools/traffic_from_pmc.py" 'g16_conv|g16_pair|g16_chain|g16_ups|g16_rw|g16_pp' "$O/pmc_fetch/p_counter_collection.csv" "$O/pmc_write/p_counter_collection.csv" f16s 64 489 > "$O/traffic.json" || true
+python3 "$R/tools/traffic_from_pmc.py" 'g16_conv|g16_pair|g16_chain|g16_ups|g16_rw|g16_pp|g16_rc' "$O/pmc_fetch/p_counter_collection.csv" "$O/pmc_write/p_counter_collection.csv" f16s 64 489 > "$O/traffic.json" || true
 cp "$O/traffic.json" "$R/profiles/traffic.json"   # the bench lines below report THIS build's measured traffic
 python3 "$R/bench.py" --steps 20 --warmup 5 > "$O/bench.json" 2>> "$O/bench.err"
 python3 "$R/bench.py" --workload C2 --steps 10 --cpu-runs 1 > "$O/bench_c2.json" 2>> "$O/bench.err"

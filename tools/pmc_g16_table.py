@@ -7,7 +7,7 @@ import csv
 import re
 import sys
 
-FAM = re.compile(r"(g16_convp|g16_conv|g16_pair|g16_rw|g16_pp|g16_chain|g16_ups|conv1d_f32_mfma|conv_frame_f16s|conv_frame_splitk|attn_relpos_f16s|attn_pack_f16s)<([^>]*)>")
+FAM = re.compile(r"(g16_convp|g16_conv|g16_pair|g16_rw|g16_rc|g16_pp|g16_chain|g16_ups|conv1d_f32_mfma|conv_frame_f16s|conv_frame_splitk|attn_relpos_f16s|attn_pack_f16s)<([^>]*)>")
 MANGLED = re.compile(r"_ZN3vsp\d+(attn_relpos_f16s|attn_pack_f16s)I((?:Li[0-9]+E)+)E")
 tot = collections.OrderedDict()   # family -> counter -> sum
 cnt = collections.Counter()

@@ -11,7 +11,7 @@ rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if 'conv_post' in r['Kernel_Name']]
 seg = rows[idx[-2] + 1: idx[-1] + 1]
-gen = [r for r in seg if any(k in r['Kernel_Name'] for k in ('g16_conv', 'g16_pair', 'g16_chain', 'g16_ups', 'g16_rw', 'g16_pp'))]
+gen = [r for r in seg if any(k in r['Kernel_Name'] for k in ('g16_conv', 'g16_pair', 'g16_chain', 'g16_ups', 'g16_rw', 'g16_pp', 'g16_rc'))]
 c0 = 512
 rates = [8, 8, 4, 2]; uk = [16, 16, 4, 4]; ks = [3, 7, 11]
 specs = []
@@ -33,7 +33,7 @@ gi = 0
 si = 0
 while si < len(specs) and gi < len(gen):
     name, kind, co, ci, K, N, Nout, res = specs[si]
-    if 'g16_chain' in gen[gi]['Kernel_Name'] and kind == 'pair':
+    if ('g16_chain' in gen[gi]['Kernel_Name'] or 'g16_rc' in gen[gi]['Kernel_Name']) and kind == 'pair':
         merged.append((name[:-2] + 'ch', 'chain', co, ci, K, N, Nout, res, 3))
         si += 3
     elif 'g16_pp' in gen[gi]['Kernel_Name'] and kind == 'conv' and name.endswith('a'):

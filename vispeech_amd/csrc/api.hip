@@ -115,6 +115,7 @@ struct Run {
     a.slope = 0.1f;                                    // modules.LRELU_SLOPE (reference modules.py:17)
     a.acc_prev = acc_prev ? 1 : 0; a.div = div;
     a.terms = ctx->gen_mode == 2 ? 1 : 3;
+    a.ring = ctx->chain_ring ? 1 : 0;
     const bool prof = prof_begin(VSP_PROF_GENERATOR);
     chk(launch_g16_chain(a, B, s), "g16_chain");
     if (prof) {
@@ -591,6 +592,7 @@ int vsp_create(const vsp_config* cfg, int device, vsp_ctx** out) {
   if (const char* e = getenv("VSP_TIMG")) ctx->t_img = atoi(e) != 0;   // 0: ResBlock intermediates as fp32 tensors (second implementation)
   if (const char* e = getenv("VSP_PP")) ctx->pp_pairs = atoi(e) != 0;  // 0: the 128-channel stage's k3 / k7 pairs as two launches
   if (const char* e = getenv("VSP_PAIR")) ctx->pair_ring = !strcmp(e, "ring");
+  if (const char* e = getenv("VSP_CHAIN_RING")) ctx->chain_ring = atoi(e) != 0;
   if (const char* e = getenv("VSP_CHAIN")) ctx->chain_mask = atoi(e);
 #ifdef VSP_EXPERIMENTS
   if (const char* e = getenv("VSP_ATT_KSPLIT")) ctx->att_ksplit = atoi(e);
@@ -1695,6 +1697,7 @@ int vsp_cl_resblock(void* stream, int B, int T, int C, int K, int n_pairs, const
     for (int i = 0; i < 2 * n_pairs; ++i) { a.w[i] = static_cast<const uint16_t*>(w[i].p); a.b[i] = static_cast<const float*>(bias[i].p); }
     for (int p = 0; p < n_pairs; ++p) a.dil[p] = dilations[p];
     a.np = n_pairs; a.C = C; a.K = K; a.T = T; a.slope = 0.1f; a.acc_prev = 0; a.div = 1.f; a.terms = terms;
+    if (const char* ev = getenv("VSP_CHAIN_RING")) a.ring = atoi(ev) != 0;   // (read per call: the test API has no context)
     e = launch_g16_chain(a, B, s);
   } else {
     // the running y ping-pongs between two buffers (a tile reads halo rows its neighbour writes)

@@ -1289,6 +1289,8 @@ hipError_t launch_g16_chain(const ClChainArgs& a0, int B, hipStream_t s) {
   if (!g16_chain_supported(a.C, a.K, a.dil, a.np) || a.T <= 0 || B <= 0 || (a.x_bs & 3) || (a.o_bs & 3) ||
       (reinterpret_cast<uintptr_t>(a.x) & 15) || (reinterpret_cast<uintptr_t>(a.out) & 15) || a.x == a.out)
     return hipErrorInvalidValue;
+  // round 4: the kernel-3 ResBlock of the 32-channel stage as a role pipeline with the weights in registers (gen16_rc.hip)
+  if (!a.ring && g16_rc_supported(a.C, a.K, a.dil, a.np, a.terms, a.acc_prev)) return launch_g16_rc(a, B, s);
   a.halo = g16_chain_halo(a.K, a.dil, a.np);
   // few, fat waves (64 columns x all channels each, up to 256 registers).  32 channels: one 8-wave block of 512
   // columns per CU when the halo would eat more than a quarter of a 256-column tile, else two 4-wave blocks of 256

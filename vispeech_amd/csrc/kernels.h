@@ -122,8 +122,13 @@ struct ClChainArgs {
   float slope;
   int acc_prev; float div;
   int terms;
+  int ring;                                 // 1: the LDS-ring chain kernel (g16_chain) even where the register-weights one exists
   int tiles, halo;                          // set by the launcher: tiles per utterance, columns recomputed per side
 };
+// the kernel-3 ResBlock of the 32-channel stage as a role pipeline with the weights in registers (gen16_rc.hip);
+// launch_g16_chain routes there unless ClChainArgs::ring (VSP_CHAIN_RING=1) asks for the LDS-ring chain (bit-identical)
+bool g16_rc_supported(int C, int K, const int* dil, int np, int terms, int acc_prev);
+hipError_t launch_g16_rc(const ClChainArgs& a, int B, hipStream_t s);
 bool g16_chain_supported(int C, int K, const int* dil, int np);
 hipError_t launch_g16_chain(const ClChainArgs& a, int B, hipStream_t s);
 hipError_t launch_g16_conv(const ClConvArgs& a, int B, hipStream_t s);

@@ -116,6 +116,7 @@ struct vsp_ctx {
   bool t_img = true;              // ResBlock intermediates of the per-convolution stages as operand images (VSP_TIMG=0: fp32)
   bool pp_pairs = true;           // k3 / k7 conv pairs of the 128-channel stage as one launch (g16_pp; VSP_PP=0: two launches)
   bool pair_ring = false;         // VSP_PAIR=ring: the LDS-ring pair kernel on the 32-channel stage instead of g16_rw
+  bool chain_ring = false;        // VSP_CHAIN_RING=1: the LDS-ring chain kernel (g16_chain) instead of g16_rc
   int64_t noise_first = 0;        // stream index of element 0 of a library-drawn noise tensor (vsp_set_noise_offset)
   bool adopted_pending = false;   // an adopted arena whose header has not been checked yet (vsp_commit_adopted_weights)
   int gen_mode = 1;  // 0: f32 MFMA channel-major generator, 1: split-f16 (fp32-accurate) channels-last generator,
