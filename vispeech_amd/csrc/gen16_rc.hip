@@ -101,10 +101,7 @@ __global__ void __launch_bounds__(512) g16_rc(ClChainArgs a, int total_tiles) {
   //      reads requested a whole tap ahead (g16_rw's form).  prime() requests a group's first fragments and its bias: at
   //      the top of an item for its first group, from inside the previous group's last tap otherwise.
   f16x8 nBh, nBl;
-  f32x4 nh0, nh1;
-  auto prime = [&](unsigned baddr, unsigned bias_a) {
-    nh0 = __builtin_bit_cast(f32x4, g16_lds_read<0>(bias_a));
-    nh1 = __builtin_bit_cast(f32x4, g16_lds_read<64>(bias_a));
+  auto prime = [&](unsigned baddr, unsigned) {
     nBh = g16_lds_read<0>(baddr);
     nBl = g16_lds_read<RC_IMG>(baddr);
   };
@@ -112,7 +109,9 @@ __global__ void __launch_bounds__(512) g16_rc(ClChainArgs a, int total_tiles) {
                         f32x4& hh1, f32x4& cr0, f32x4& cr1) {
     constexpr int p = decltype(P)::value;
     constexpr bool last = decltype(LAST)::value;
-    hh0 = nh0; hh1 = nh1;
+    // (the bias straight into the accumulators: requested behind the group's primed fragments, it is the youngest read)
+    hh0 = __builtin_bit_cast(f32x4, g16_lds_read<0>(bias_a));
+    hh1 = __builtin_bit_cast(f32x4, g16_lds_read<64>(bias_a));
     cr0 = f32x4{0.f, 0.f, 0.f, 0.f}; cr1 = cr0;
     __builtin_amdgcn_s_setprio(1);
     f16x8 Bh[2], Bl[2];
@@ -126,7 +125,7 @@ __global__ void __launch_bounds__(512) g16_rc(ClChainArgs a, int total_tiles) {
         g16_lgkmcnt<2>();
       } else if constexpr (!last) {
         prime(bnext, bias_a);
-        g16_lgkmcnt<4>();
+        g16_lgkmcnt<2>();
       } else {
         g16_lgkmcnt<0>();
       }
@@ -193,8 +192,10 @@ __global__ void __launch_bounds__(512) g16_rc(ClChainArgs a, int total_tiles) {
   // an activated, split D-layout tile pair (channels 4 q4 .. + 3 and 16 + 4 q4 .. + 3 of column `col`) -> image; columns
   // outside the utterance are the next convolution's zero padding.  A lane's four channels 16 i + 4 q4 .. + 3 sit in plane
   // 2 i + (q4 >> 1) at byte 8 (q4 & 1) of the row's 16
-  auto write_image = [&](char* img, int col, int q4, bool valid, f32x4 v0, f32x4 v1) {
-    if (!valid) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
+  auto write_image = [&](auto MASK, char* img, int col, int q4, int t, f32x4 v0, f32x4 v1) {
+    if constexpr (decltype(MASK)::value) {
+      if (!(t >= 0 && t < a.T)) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
+    }
     f16x4 eh, el;
     char* dst = img + (q4 >> 1) * RC_PL + (RC_GRD + col) * 16 + 8 * (q4 & 1);
     g16_split4(v0, slope, true, eh, el);
@@ -218,7 +219,7 @@ __global__ void __launch_bounds__(512) g16_rc(ClChainArgs a, int total_tiles) {
   f32x4 xa[RC_G][2], xb[RC_G][2];          // xa: the tile of this body's passes 0 / 1 (tile m); xb: tile m - 1
 
   // one ITEM of a role: (tile m, pass P) at iteration j -- conv1 waves run item (j), conv2 waves item (j - 1)
-  auto conv1_item = [&](auto P, int m, int j, int ln) {
+  auto conv1_item_m = [&](auto P, auto MASK, int m, int j, int ln) {
     constexpr int p = decltype(P)::value;
     const int q4 = ln >> 4, l15 = ln & 15;
     const TileAt at = tile_at(m);
@@ -234,10 +235,10 @@ __global__ void __launch_bounds__(512) g16_rc(ClChainArgs a, int total_tiles) {
                  hh0, hh1, cr0, cr1);
       const int col = wr * RC_CW + 16 * g + l15;
       const int t = at.tb + col;
-      write_image(ti, col, q4, t >= 0 && t < a.T, hh0 + cr0 * (1.f / 2048.f), hh1 + cr1 * (1.f / 2048.f));
+      write_image(MASK, ti, col, q4, t, hh0 + cr0 * (1.f / 2048.f), hh1 + cr1 * (1.f / 2048.f));
     });
   };
-  auto conv2_item = [&](auto P, int m, int j, int ln, f32x4 (&xr)[RC_G][2]) {
+  auto conv2_item_m = [&](auto P, auto MASK, int m, int j, int ln, f32x4 (&xr)[RC_G][2]) {
     constexpr int p = decltype(P)::value;
     const int q4 = ln >> 4, l15 = ln & 15;
     const TileAt at = tile_at(m);
@@ -281,7 +282,7 @@ __global__ void __launch_bounds__(512) g16_rc(ClChainArgs a, int total_tiles) {
       v1 += xr[g][1];
       if constexpr (p + 1 < RC_NP) {
         xr[g][0] = v0; xr[g][1] = v1;                           // x_{p+1}
-        write_image(xw, col, q4, t >= 0 && t < a.T, v0, v1);    // ... and the next pass's input image
+        write_image(MASK, xw, col, q4, t, v0, v1);    // ... and the next pass's input image
       } else {
         const int off = (col >= H && col < H + R && t < a.T) ? (t * 32 + 4 * q4) * 4 : G16_OOR;
         if constexpr (ACC) { v0 += g16_as_f32x4(prv[g & 1][0]); v1 += g16_as_f32x4(prv[g & 1][1]); }
@@ -290,6 +291,22 @@ __global__ void __launch_bounds__(512) g16_rc(ClChainArgs a, int total_tiles) {
         __builtin_amdgcn_raw_buffer_store_b128(g16_as_u32x4(v1), ro, off, 64, 0);
       }
     });
+  };
+
+  // tiles that lie inside their utterance (all but the first and the last of an utterance) skip the zero masks of the
+  // image writes: a UNIFORM branch between two instantiations of an item (a run-time flag inside one instantiation cost
+  // four spilled registers and 17 %)
+  auto tile_inside = [&](int m) {
+    const TileAt at = tile_at(m);
+    return at.tb >= 0 && at.tb + RC_BT <= a.T;
+  };
+  auto conv1_item = [&](auto P, int m, int j, int ln) {
+    if (tile_inside(m)) conv1_item_m(P, std::false_type{}, m, j, ln);
+    else conv1_item_m(P, std::true_type{}, m, j, ln);
+  };
+  auto conv2_item = [&](auto P, int m, int j, int ln, f32x4 (&xr)[RC_G][2]) {
+    if (tile_inside(m)) conv2_item_m(P, std::false_type{}, m, j, ln, xr);
+    else conv2_item_m(P, std::true_type{}, m, j, ln, xr);
   };
 
   // ================= the pipeline: body m = iterations 3m, 3m + 1, 3m + 2 =================
