@@ -117,9 +117,27 @@ __device__ __forceinline__ void g16_for(F&& f) {
 // packed hi is a subnormal f16 that keeps fewer than 11 bits while lo is still taken against the fp32-truncated value,
 // so hi + lo loses up to 2^-24 ABSOLUTE per operand there -- below the fp32 accumulation noise of any activation that
 // matters (vocoder activations are O(1e-2 .. 1)); tests/test_cl_ops.py keeps a small-amplitude case.
+// G16_SPLIT_PLAIN (late round 4): the subtraction, the two scalings as PLAIN f32 instructions (asm, so that hipcc does not
+// SLP-pack them): beside an MFMA stream a v_pk_*_f32 costs far more issue time than the two plain instructions it
+// replaces (MI355X_MICROARCH.md, constants table: "an anti-lever beside MFMAs"), and these kernels' vector work runs
+// beside MFMAs.  Same arithmetic, same bits.  CAUTION: hipcc's hazard recognizer does not see into inline asm -- an asm
+// instruction that reads an MFMA RESULT register directly gets no wait states and reads a stale value (tried: hh + cr /
+// 2048 as asm v_fma_f32: errors of 1e-4).  Every caller hands g16_split4 values that a compiler-generated vector
+// instruction has produced (the fold, a select).
+#ifndef G16_SPLIT_PLAIN
+#define G16_SPLIT_PLAIN 1
+#endif
 __device__ __forceinline__ void g16_split2(f32x2 x, f16x2& h, f16x2& l) {
   const f32x2 hf = {__uint_as_float(__float_as_uint(x.x) & 0xffffe000u), __uint_as_float(__float_as_uint(x.y) & 0xffffe000u)};
+#if G16_SPLIT_PLAIN
+  f32x2 lf;
+  asm("v_sub_f32 %0, %1, %2" : "=v"(lf.x) : "v"(x.x), "v"(hf.x));
+  asm("v_sub_f32 %0, %1, %2" : "=v"(lf.y) : "v"(x.y), "v"(hf.y));
+  asm("v_mul_f32 %0, 0x45000000, %1" : "=v"(lf.x) : "v"(lf.x));          // * 2048
+  asm("v_mul_f32 %0, 0x45000000, %1" : "=v"(lf.y) : "v"(lf.y));
+#else
   const f32x2 lf = (x - hf) * 2048.f;
+#endif
   h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(hf.x, hf.y));
   l = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(lf.x, lf.y));
 }
@@ -128,7 +146,13 @@ __device__ __forceinline__ void g16_split4(const f32x4 v, float slope, bool act,
   for (int k = 0; k < 2; ++k) {
     f32x2 x = {v[2 * k], v[2 * k + 1]};
     if (act) {
+#if G16_SPLIT_PLAIN
+      f32x2 y;
+      asm("v_mul_f32 %0, %1, %2" : "=v"(y.x) : "s"(slope), "v"(x.x));
+      asm("v_mul_f32 %0, %1, %2" : "=v"(y.y) : "s"(slope), "v"(x.y));
+#else
       const f32x2 y = x * slope;
+#endif
       asm("v_max_f32 %0, %1, %2" : "=v"(x.x) : "v"(x.x), "v"(y.x));   // leaky-relu = max(x, slope*x), 0 <= slope <= 1
       asm("v_max_f32 %0, %1, %2" : "=v"(x.y) : "v"(x.y), "v"(y.y));
     }

@@ -30,6 +30,7 @@ namespace vsp {
 
 namespace {
 constexpr int RC_K = 3, RC_NP = 3;
+constexpr bool RC_PRIO = true;    // (the MFMA clusters at raised priority: 2.66 against 2.69 ms without)
 constexpr int RC_BT = 192;                 // columns per tile
 constexpr int RC_CW = RC_BT / 4;           // columns per role wave
 constexpr int RC_G = RC_CW / 16;           // 16-column groups per role wave and tile
@@ -113,7 +114,7 @@ __global__ void __launch_bounds__(512) g16_rc(ClChainArgs a, int total_tiles) {
     hh0 = __builtin_bit_cast(f32x4, g16_lds_read<0>(bias_a));
     hh1 = __builtin_bit_cast(f32x4, g16_lds_read<64>(bias_a));
     cr0 = f32x4{0.f, 0.f, 0.f, 0.f}; cr1 = cr0;
-    __builtin_amdgcn_s_setprio(1);
+    if constexpr (RC_PRIO) __builtin_amdgcn_s_setprio(1);
     f16x8 Bh[2], Bl[2];
     Bh[0] = nBh; Bl[0] = nBl;
     g16_for<K>([&](auto T) {
@@ -138,7 +139,7 @@ __global__ void __launch_bounds__(512) g16_rc(ClChainArgs a, int total_tiles) {
       cr1 = G16_MFMA(Wh[p][tap][1], Bl[cur], cr1);
       __builtin_amdgcn_sched_barrier(0);
     });
-    __builtin_amdgcn_s_setprio(0);
+    if constexpr (RC_PRIO) __builtin_amdgcn_s_setprio(0);
   };
 
   // ---- tiles: (b, tile) of the run's m-th tile; tb = time of its column 0
