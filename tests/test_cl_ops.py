@@ -176,6 +176,31 @@ def test_cl_resblock_chain_role_pipeline_long_rows(lib, dils, b, t, monkeypatch)
     assert rel_err(outs[2].numpy(), torch_resblock(x, ws, bs, dils, k)) <= TOL
 
 
+@pytest.mark.parametrize("c,k,dils,mode,b,t", [(128, 3, (1, 3, 5), 1, 8, 30000), (128, 7, (3, 5), 1, 6, 29000),
+                                                (32, 3, (1, 3, 5), 2, 16, 60000), (32, 11, (1, 5), 1, 8, 60000)])
+def test_fused_kernels_repeat_bit_for_bit(lib, c, k, dils, mode, b, t):
+    """Race screen for the kernels that order LDS traffic by counted waits (g16_pp, g16_rc, g16_rw): a read that passes its
+    wait one phase early is right whenever the LDS-DMA happens to have landed.  Twelve launches of a chip-filling problem,
+    interleaved with a memory-bound kernel that changes the DMA latencies, must give the SAME bits every time -- the bits of
+    the per-convolution path."""
+    r = np.random.Generator(np.random.PCG64(c * 7 + k))
+    x = r.standard_normal((b, t, c)).astype(np.float32)
+    ws = [(r.standard_normal((c, c, k)) / np.sqrt(c * k)).astype(np.float32) for _ in range(2 * len(dils))]
+    bs = [r.standard_normal(c).astype(np.float32) * 0.1 for _ in range(2 * len(dils))]
+    xd = torch.from_numpy(x).cuda()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    darr = (C.c_int * len(dils))(*dils)
+    ref = torch.empty((b, t, c), device="cuda")
+    assert lib.vsp_cl_resblock(stream, b, t, c, k, len(dils), darr, P(xd), host_ptrs(ws), host_ptrs(bs), 0, 3, P(ref)) == 0
+    noise = torch.empty(64 * 1024 * 1024, device="cuda")
+    for i in range(12):
+        out = torch.full((b, t, c), float("nan"), device="cuda")
+        if i % 2:
+            noise.add_(1.0)                                     # (stream-ordered before the launch: cold caches, busy HBM)
+        assert lib.vsp_cl_resblock(stream, b, t, c, k, len(dils), darr, P(xd), host_ptrs(ws), host_ptrs(bs), mode, 3, P(out)) == 0
+        assert torch.equal(out, ref), (i, float((out - ref).abs().max()))
+
+
 PIPE_CASES = [(128, 3, (1, 5), 4, 16000), (128, 11, (3,), 5, 13000), (256, 7, (5, 1), 3, 11000)]
 
 
