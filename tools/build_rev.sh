@@ -11,5 +11,7 @@ mkdir -p "$R/build/$D"
 cd "$T/vispeech_amd/csrc"
 SRCS="$(sed -n 's/^SRCS *[:+]*= *//p' Makefile)"
 # shellcheck disable=SC2086
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -shared $(for f in $SRCS; do case "$f" in *.cpp) echo "-x hip $f";; *) echo "$f";; esac; done) -o "$R/build/$D/libvispeech_hip.so" 2>&1 | grep -E "error" || true
+EXTRA="$(grep -q -- '-packed-fp32-ops' Makefile && echo '-Xclang -target-feature -Xclang -packed-fp32-ops' || true)"   # (the revision's own code-generation flags)
+# shellcheck disable=SC2086
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $EXTRA -shared $(for f in $SRCS; do case "$f" in *.cpp) echo "-x hip $f";; *) echo "$f";; esac; done) -o "$R/build/$D/libvispeech_hip.so" 2>&1 | grep -E "error" || true
 ls -la "$R/build/$D/libvispeech_hip.so"

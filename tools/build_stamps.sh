@@ -11,6 +11,6 @@ for V in "g16stamps G16_STAMPS" "rwstamps RW_STAMPS" "ppstamps PP_STAMPS"; do
   if [ -n "${ONLY:-}" ] && [ "$ONLY" != "$1" ]; then continue; fi
   mkdir -p ../../build/$1
   # shellcheck disable=SC2086
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -D$2 -shared $SRCS -o ../../build/$1/libvispeech_hip.so 2>&1 | grep -E "error" || true
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Xclang -target-feature -Xclang -packed-fp32-ops -D$2 -shared $SRCS -o ../../build/$1/libvispeech_hip.so 2>&1 | grep -E "error" || true
   ls -la ../../build/$1/libvispeech_hip.so
 done
