@@ -244,7 +244,10 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
   // into registers, its LDS-DMA pieces, window staging) with an MFMA phase (the step's MW*NW*3 MFMAs back to back),
   // one barrier between phases; the second half of the block runs one phase behind the first (it starts with a
   // barrier), so a SIMD's matrix core always has one wave multiplying while its partner does the memory work.
-  if (wave >= NWV / 2) G16_BARRIER();
+  // Priority (late round 4): STATIC -- the second-dispatched half of the block loses the SIMD's issue arbitration (priority,
+  // then age) on every phase; one s_setprio 1 for it here and no per-phase flips (MI355X_MICROARCH.md, "Two waves per
+  // SIMD", item 4) instead of a raised priority around every MFMA cluster: s0 -0.17 ms, s1 -0.3 ms, same box.
+  if (wave >= NWV / 2) { G16_BARRIER(); __builtin_amdgcn_s_setprio(1); }
 
   int chunk = 0, tap = 0, slot = 0;   // of the current step
   for (int s = 0; s < S; ++s) {
@@ -293,7 +296,6 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
     }
     // ================= MFMA phase of step s =================
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
     g16_for<NW>([&](auto J) {
       constexpr int j = decltype(J)::value;
       g16_for<MW>([&](auto I) {
@@ -305,7 +307,6 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
         }
       });
     });
-    __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     G16_STAMP();                                            // 6 + 4 s: MFMAs issued
     // (the second half skips the barrier behind its LAST MFMA phase: nothing in the LDS is read after it, and waiting there

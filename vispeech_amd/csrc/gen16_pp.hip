@@ -186,7 +186,8 @@ __global__ void __launch_bounds__(512) g16_pp(ClPairArgs a) {
   for (int i = 0; i < MW; ++i) asm volatile("" ::"v"(bv2[i]));   // (retires the bias loads here, not inside the loops)
   PP_STAMP(4);
   G16_BARRIER();
-  if (wm) G16_BARRIER();            // the second half runs one phase behind
+  // (static priority for the second-dispatched half, no per-phase flips: gen16.hip, g16_conv)
+  if (wm) { G16_BARRIER(); __builtin_amdgcn_s_setprio(1); }            // the second half runs one phase behind
   PP_STAMP(5);
 
   int slot = 0, gs = 0;
@@ -238,7 +239,6 @@ __global__ void __launch_bounds__(512) g16_pp(ClPairArgs a) {
       }
       // ================= MFMA phase =================
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
       if (!(diag & 16))
       g16_for<NW>([&](auto J) {
         constexpr int j = decltype(J)::value;
@@ -249,7 +249,6 @@ __global__ void __launch_bounds__(512) g16_pp(ClPairArgs a) {
           cr[i][j] = G16_MFMA(Ah[i], Bl[j], cr[i][j]);
         });
       });
-      __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       PP_STAMP(13);                                            // MFMAs issued
       // (conv2: the second half skips the barrier behind its LAST MFMA phase -- its epilogue would otherwise wait for
