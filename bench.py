@@ -69,6 +69,10 @@ def parse(argv=None):
                    help="C3 and the other per-rank workloads: every rank synthesises its OWN batch (weak scaling) instead of "
                         "its shard_range slice of ONE batch (strong scaling, the default: BASELINE.json's metric is one "
                         "64-utterance batch at 1 / 2 / 4 / 8 GPUs)")
+    p.add_argument("--shard-of", type=int, default=0,
+                   help="one GPU, no process group: synthesise ONLY rank --shard-rank's shard_range slice of the batch under the "
+                        "GLOBAL frame padding -- the per-GPU operating point a --gpus N run lands on (profiles/r05_per_rank_*)")
+    p.add_argument("--shard-rank", type=int, default=0)
     p.add_argument("--dist", action="store_true",
                    help="initialise torch.distributed (RCCL) even at --gpus 1: the weight broadcast, the frame-count "
                         "all-reduce and the waveform gather run through the collectives with one rank")
@@ -209,6 +213,11 @@ def main():
     args = parse()
     if "RANK" not in os.environ and (args.gpus > 1 or args.dist):
         sys.exit(self_launch(args))
+    # a rank that hangs must END, loudly and non-zero (torch.distributed.run then takes the other ranks and the parent
+    # down with it): after VSP_BENCH_DUMP_AFTER seconds (default 900) every thread's Python stack goes to stderr and the
+    # process exits -- a hung collective never outlives the run, and the dump says where it hung
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("VSP_BENCH_DUMP_AFTER", "900")), exit=True)
     import numpy as np
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -264,6 +273,11 @@ def main():
     batch = synth_batch(**wl)
     B_all = int(batch["phonemes"].shape[0])
     lo, hi = shard_range(B_all, rank, world) if sharded_global else (0, B_all)
+    if args.shard_of:
+        if world != 1 or args.workload == "C5" or args.controls == "none" or args.weak:
+            raise SystemExit("--shard-of: one GPU, a sharded workload, durations supplied")
+        sharded_global = True
+        lo, hi = shard_range(B_all, args.shard_rank, args.shard_of)
     sl = slice(lo, hi)
     B = hi - lo
     t = lambda x: torch.from_numpy(np.asarray(x)).to(dev)
@@ -282,6 +296,8 @@ def main():
         frames_local = np.asarray(eng.frame_lengths_host(enc["frame_lengths"])[0], dtype=np.int64)
     tf_local = int(frames_local.max()) if B else 0
     tf_global = global_max(tf_local, dev)
+    if args.shard_of:
+        tf_global = int(batch["frame_lengths"].max())          # what the all-reduce MAX of the N ranks would return
     valid_samples = 512 * int(frames_local.sum())
     r = np.random.Generator(np.random.PCG64(wl["seed"] * 7919 + 13))
     noise_np = np.zeros((B_all if sharded_global else B, dims.inter_channels, tf_global), dtype=np.float32)
@@ -342,10 +358,29 @@ def main():
         for _ in range(args.profile_steps):
             step()
         drain()
+        fams = eng.profile_read_families(_lib.PROF_GENERATOR)
         for name, cls in (("generator", _lib.PROF_GENERATOR), ("attention", _lib.PROF_ATTENTION), ("frame", _lib.PROF_FRAME)):
             n, ms, fl, by, bx = eng.profile_read(reset=True, cls=cls)
             prof[name] = dict(launches=n // args.profile_steps, ms=ms / args.profile_steps, flops=fl / args.profile_steps,
                               bytes=by / args.profile_steps, bytes_ext=bx / args.profile_steps)
+        if fams:
+            # the kernel family with the largest share of the step (HIP events around each of its launches): what a reader
+            # recomputes from profiles/*kernel_stats.csv (name, launches per step, average duration)
+            KN = {("pair", 128): "g16_pp (ResBlock conv pairs, 128 channels)", ("pair", 64): "g16_pair<2,2,3,8,2> (ResBlock conv pairs, 64 channels)",
+                  ("pair", 32): "g16_rw (ResBlock conv pairs, 32 channels, weights in registers)",
+                  ("chain", 32): "g16_rc (whole k3 ResBlock, 32 channels)", ("conv", 256): "g16_conv / g16_convp (256-channel ResBlock convolutions)",
+                  ("conv", 128): "g16_conv (128-channel k11 ResBlock convolutions)"}
+            f = fams[0]
+            k = args.profile_steps
+            avg = f["ms"] / max(f["launches"], 1)
+            prof["dominant"] = {
+                "name": KN.get((f["kind"], f["channels"]), f"{f['kind']} C={f['channels']}"),
+                "launches": f["launches"] // k, "avg_launch_ms": avg, "ms_per_step": f["ms"] / k,
+                "alg_flops_per_launch": f["flops"] / max(f["launches"], 1), "alg_bytes_per_launch": f["bytes"] / max(f["launches"], 1),
+                "alg_tflops": f["flops"] / max(f["ms"], 1e-9) / 1e9, "alg_gbs": f["bytes"] / max(f["ms"], 1e-9) / 1e6,
+                "alg_frac_mfma": f["flops"] / max(f["ms"], 1e-9) / 1e9 / PEAK_F16_MFMA_TFLOPS,
+                "alg_frac_hbm": f["bytes"] / max(f["ms"], 1e-9) / 1e6 / PEAK_HBM_GBS,
+                "families_ms_per_step": {f"{x['kind']}{x['channels']}": round(x["ms"] / k, 3) for x in fams}}
         eng.profile(False)
         if use_dist:
             dist.barrier()
@@ -386,6 +421,7 @@ def main():
                        "utterances_per_gpu": B, "global_batch": B_all * (1 if sharded_global else world),
                        "padded_frames": tf_global, "valid_samples_per_step": int(total_valid),
                        "parallelism": f"shard{world}", "generator": gen_mode, "controls": args.controls},
+            "emulated_rank": ({"rank": args.shard_rank, "of": args.shard_of, "utterances": [lo, hi]} if args.shard_of else None),
             "n_ranks_seen": n_ranks_seen,
             "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
             "gather": ({"bytes_into_rank0_per_step": int(4 * 512 * tf_global * (B_all * (1 if sharded_global else world) - B)),
@@ -404,11 +440,12 @@ def main():
             gbs = g["bytes"] / (g["ms"] * 1e-3) / 1e9 if g["ms"] > 0 else 0.0            # SURVEY 8d bytes / time
             mf = {"f32": 1.0, "f16": 1.0}.get(gen_mode, 3.0)                               # MFMA FLOPs issued per algorithmic FLOP
             peak = PEAK_F32_MFMA_TFLOPS if gen_mode == "f32" else PEAK_F16_MFMA_TFLOPS
-            f_hbm, f_mfma = gbs / PEAK_HBM_GBS, mf * tfl / peak
-            # the bound is the roof the kernels sit closer to, from measured facts: issued matrix FLOP/s against the
-            # dense f16 peak vs layer-boundary bytes against the HBM peak
-            roof = ({"bound": "mfma", "achieved": mf * tfl, "peak": peak, "unit": "TFLOP/s", "frac": f_mfma}
-                    if f_mfma >= f_hbm else
+            f_hbm, f_mfma, f_alg = gbs / PEAK_HBM_GBS, mf * tfl / peak, tfl / peak
+            # `frac` is the ALGORITHMIC figure: the larger of algorithmic FLOPs / dense MFMA peak and
+            # SURVEY 8d layer-boundary bytes / HBM peak, `bound` naming which roof that is.  The ISSUED matrix rate (three
+            # f16 MFMAs per fp32-accurate product) stays beside it as `mfma_issue_frac`.
+            roof = ({"bound": "mfma", "achieved": tfl, "peak": peak, "unit": "TFLOP/s", "frac": f_alg}
+                    if f_alg >= f_hbm else
                     {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": f_hbm})
             roof.update({
                 "traffic": None,
@@ -417,7 +454,8 @@ def main():
                 "alg_tflops": tfl, "alg_frac": tfl / peak, "alg_flops_per_launch": g["flops"] / max(g["launches"], 1),
                 "alg_gbs": gbs, "alg_bytes_per_launch": g["bytes"] / max(g["launches"], 1),
                 "alg_gbs_with_residual_reads": g["bytes_ext"] / (g["ms"] * 1e-3) / 1e9 if g["ms"] > 0 else 0.0,
-                "hbm_frac": f_hbm, "mfma_issue_frac": f_mfma,
+                "hbm_frac": f_hbm, "mfma_issue_frac": f_mfma, "mfma_issue_tflops": mf * tfl,
+                "dominant_kernel": prof.get("dominant"),
                 "mfma_frac_of_measured_random_data_ceiling": mf * tfl / MEASURED_F16_MFMA_CEILING_TFLOPS if gen_mode != "f32" else None,
                 "hbm_frac_whole_path": value / world * ALG_BYTES_PER_SAMPLE / (PEAK_HBM_GBS * 1e9),
                 "note": "achieved / alg_gbs count SURVEY 8d's layer-boundary bytes (input once + output once per convolution; "
@@ -452,6 +490,7 @@ def main():
                             and tr.get("lib_sha256") == lib_sha256():
                         roof["traffic"] = tr["hbm_bytes_per_launch"]
                         roof["traffic_source"] = "previous PMC pass: " + str(tr.get("source"))
+                        roof["traffic_launches"] = tr.get("launches_per_step")   # (the g16_* launches: conv_pre runs on the frame-rate kernel, outside the PMC kernel filter)
                         roof["hbm_measured_gbs"] = tr["hbm_bytes_per_launch"] * tr.get("launches_per_step", g["launches"]) / (g["ms"] * 1e-3) / 1e9
                 except Exception:
                     pass

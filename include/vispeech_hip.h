@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define VSP_ABI_VERSION 4
+#define VSP_ABI_VERSION 5
 
 enum {
   VSP_OK = 0,
@@ -269,7 +269,11 @@ int vsp_rq_spline(void* stream, int64_t n, int nb, const float* x, const float* 
 /* n standard-normal draws (device, float32): element i of the Philox4x32-10 stream keyed by `seed` (counter i / 4,
  * word i % 4, Box-Muller pairs).  A function of (seed, i) only.  This is the draw vsp_decode / vsp_infer make when
  * their noise argument is NULL; it replaces torch.randn_like (reference models.py:718, 240) for C callers and is not
- * bit-compatible with torch's generator. */
+ * bit-compatible with torch's generator.
+ * STREAM CHANGE (late round 4, first released under ABI 5): the uniforms behind Box-Muller are built from 23 random bits
+ * ((x + 0.5) / 2^23, strictly inside (0, 1)) instead of 24 ((x + 0.5) / 2^24 could round to exactly 1.0 in fp32 and
+ * give log(1) = 0 radii).  EVERY element of the stream differs from what ABI <= 4 libraries of rounds 1-3 drew for the
+ * same seed: audio reproduced from a stored seed is not bit-reproducible across that boundary. */
 int vsp_randn(void* stream, uint64_t seed, int64_t n, float* out);
 /* The same stream from element `first` on: out[i] = element first + i.  A shard [lo, hi) of a batch whose noise is
  * drawn by the library passes first = lo * inter * Tf and gets exactly the elements the unsharded call would draw for
@@ -278,7 +282,7 @@ int vsp_randn_at(void* stream, uint64_t seed, int64_t first, int64_t n, float* o
 /* Where in that stream the noise tensor of vsp_decode / vsp_infer (noise == NULL) starts: element 0 of the context's
  * [B][inter][Tf] tensor is stream element `first_element` (default 0).  A rank that synthesises utterances [lo, hi) of a
  * global batch sets lo * inter * Tf (Tf = the GLOBAL padded frame count): the result no longer depends on the shard
- * layout.  Sticky until changed; 0 restores the default.  (Added in round 4; ABI 4 callers are unaffected.) */
+ * layout.  Sticky until changed; 0 restores the default.  (Added in round 4; callers that never set it are unaffected.) */
 int vsp_set_noise_offset(vsp_ctx* ctx, int64_t first_element);
 
 /* ---- mel spectrogram (reference mel_processing.py:73-112) --------------------------------- */
@@ -286,11 +290,16 @@ int vsp_set_noise_offset(vsp_ctx* ctx, int64_t first_element);
  * function's defaults (Slaney mel scale: linear below 1 kHz, logarithmic above; triangles between successive mel
  * points; Slaney area normalisation): basis_host[n_mels][n_fft / 2 + 1], computed on the host in double precision.
  * librosa is a third-party dependency of the reference (requirements.txt, no version pinned) and is not vendored:
- * this restates its published algorithm.  fmax <= 0 means sampling_rate / 2. */
+ * this restates its published algorithm.  fmax <= 0 means sampling_rate / 2.
+ * PARITY UNPINNED: neither librosa nor torchaudio is in the build image, so the basis is checked only against the
+ * oracle's independent restatement and one known answer from librosa's documentation (tests/test_mel.py). */
 int vsp_mel_filterbank(int sampling_rate, int n_fft, int n_mels, float fmin, float fmax, float* basis_host);
 /* spec_to_mel_torch (reference mel_processing.py:73-82): mel = log(clamp(basis @ spec, min = 1e-5)).
  * spec [B][n_fft / 2 + 1][T] and mel [B][n_mels][T] are device pointers; the basis is built and uploaded inside the
- * call.  vsp_spectrogram followed by this call = mel_spectrogram_torch (mel_processing.py:85-112). */
+ * call.  vsp_spectrogram followed by this call = mel_spectrogram_torch (mel_processing.py:85-112).
+ * NOT on the infer path, and unlike it this entry allocates: every call hipMallocs the basis + band tables, uploads
+ * them, synchronises the stream and frees them again (the header's "no hidden allocation, no sync" promise covers
+ * vsp_encode / vsp_decode / vsp_infer and the per-stage entries that take a workspace, not this metric helper). */
 int vsp_spec_to_mel(void* stream, int B, int T, int n_fft, int n_mels, int sampling_rate, float fmin, float fmax,
                     const float* spec, float* mel);
 
@@ -354,6 +363,23 @@ int vsp_profile_read(vsp_ctx* ctx, int64_t* launches, double* total_ms, double* 
                      int reset);
 int vsp_profile_read_class(vsp_ctx* ctx, int cls, int64_t* launches, double* total_ms, double* total_flops,
                            double* total_bytes, double* total_bytes_ext, int reset);
+/* ABI 5: the same measurement per KERNEL FAMILY of one class (so that a bench line can name its dominant kernel and a
+ * reader can recompute its figures from a rocprofv3 kernel-stats table).  family = kind | log2(channels / 32) << 3 for
+ * the generator class (channels = the launch's OUTPUT channels), 0 elsewhere:
+ *   VSP_FAM_CONV   one launch per convolution (g16_conv / g16_convp)      VSP_FAM_UPS    a transposed up-convolution
+ *   VSP_FAM_PAIR   one launch per ResBlock conv pair (g16_pp at 128 channels, g16_pair at 64, g16_rw at 32)
+ *   VSP_FAM_CHAIN  one launch per ResBlock (g16_rc / g16_chain)           VSP_FAM_PRE    conv_pre (+ cond)
+ * Fills up to `max_families` slots (families that saw no launch since the last reset are skipped) and returns the
+ * number filled (>= 0) or a negative error code.  Call it BEFORE the vsp_profile_read_class(..., reset = 1) of the
+ * same class; it never resets. */
+#define VSP_FAM_OTHER 0
+#define VSP_FAM_CONV 1
+#define VSP_FAM_UPS 2
+#define VSP_FAM_PAIR 3
+#define VSP_FAM_CHAIN 4
+#define VSP_FAM_PRE 5
+int vsp_profile_read_families(vsp_ctx* ctx, int cls, int max_families, int* family, int64_t* launches, double* total_ms,
+                              double* total_flops, double* total_bytes);
 
 #ifdef __cplusplus
 }

@@ -74,7 +74,7 @@ class _Noise:
 
 
 def run_case(net, name, batch, *, use_duration=True, use_pitch=True, use_energy=True,
-             noise_scale=0.667, max_len=None, scalar_controls=None, dur_3d=False):
+             noise_scale=0.667, max_len=None, scalar_controls=None, dur_3d=False, live_caller=False):
     stages = {}
 
     def hook(tag):
@@ -104,7 +104,15 @@ def run_case(net, name, batch, *, use_duration=True, use_pitch=True, use_energy=
     else:
         noise = batch["noise"]
     with torch.no_grad(), _Noise(noise):
-        o, x_mask, (z, z_p, m_p, logs_p), duration, f0, energy = net.infer(ph, ln, **kw)
+        if live_caller:
+            # EXACTLY the reference's one live call (train.py:281, 300-301: `for shift, energy_shift in [(1, 1)]`):
+            # durations predicted (duration_control left at None), Python-int scalar controls, max_len=1000, the
+            # default noise_scale -- on a ragged batch instead of the [:1] slice of train.py:289-293
+            shift, energy_shift = 1, 1
+            o, x_mask, (z, z_p, m_p, logs_p), duration, f0, energy = net.infer(
+                ph, ln, max_len=1000, sid=sid, pitch_control=shift, energy_control=energy_shift)
+        else:
+            o, x_mask, (z, z_p, m_p, logs_p), duration, f0, energy = net.infer(ph, ln, **kw)
     for h in hs:
         h.remove()
     tf = x_mask.shape[2]
@@ -228,7 +236,7 @@ def vc_case(net, dims):
 
 def main():
     """``make_golden.py`` rewrites everything; ``make_golden.py vc`` only voice_conversion.npz, ``vallist`` only
-    val_filelist.npz."""
+    val_filelist.npz, ``evaluate`` only evaluate_caller.npz."""
     torch.manual_seed(0)
     torch.set_num_threads(8)
     net, dims = build_reference()
@@ -244,6 +252,12 @@ def main():
         # max_len truncation + [B,1,Tp] duration tensor + pitch predicted only
         run_case(net, "maxlen_dur3d", b3, use_pitch=False, max_len=20, dur_3d=True, noise_scale=1.0)
         filelist_case(net)
+    if not only or "evaluate" in only:
+        # the reference's live caller form (train.py:300-301)
+        b3 = synth_batch(3, seed=11, mean_phonemes=9, std_phonemes=3, min_phonemes=5, max_phonemes=12,
+                         mean_frames=34, jitter_frames=6)
+        run_case(net, "evaluate_caller", b3, use_duration=False, use_pitch=False, use_energy=False,
+                 noise_scale=1.0, max_len=1000, live_caller=True)
     if not only or "vallist" in only:
         vallist_case(net)
     if not only or "spline" in only:

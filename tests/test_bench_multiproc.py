@@ -20,11 +20,13 @@ def run_bench(*extra, gpus=2, backend="gloo"):
     # plain `python bench.py --gpus N`: the parent spawns the ranks itself (what the driver runs)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1", *extra]
     env.setdefault("VSP_BENCH_PG_TIMEOUT", "120")
-    try:
-        p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
-    except subprocess.TimeoutExpired as e:          # seen once in five runs (round 3): report what the ranks said, try once more
-        print("bench.py --gpus timed out once; stderr tail:", (e.stderr or b"")[-2000:])
-        p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    # No retry.  A rank that hangs ends ITSELF after VSP_BENCH_DUMP_AFTER seconds -- every thread's Python stack goes to
+    # stderr, exit code non-zero -- and torch.distributed.run takes the other rank and the self-launching parent down with
+    # it, so a hang arrives here as a failure that says where it hung, well inside the 300 s below.  (Round 3 saw one
+    # timeout in five runs of this test; round 5 looped the same command 30x on one box, tools/loop_two_rank.sh:
+    # 30 of 30 clean -- profiles/r05_two_rank_loop.txt.)
+    env.setdefault("VSP_BENCH_DUMP_AFTER", "200")
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]                 # rank 0 prints ONE json line

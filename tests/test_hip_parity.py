@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 STAGE_TOL = 1e-5
 WAVE_TOL = 1e-4
 
-CASES = ["ragged_controls", "ragged_predictors", "maxlen_dur3d", "c1_filelist"]
+CASES = ["ragged_controls", "ragged_predictors", "maxlen_dur3d", "c1_filelist", "evaluate_caller"]
 
 
 def rel_err(a, b):
@@ -95,6 +95,27 @@ def test_infer_matches_reference_golden(net, golden_dir, case):
     for name in ("m_p", "logs_p", "z_p", "z", "F0", "energy"):
         assert errs[name] <= STAGE_TOL, (case, name, errs[name])
     assert errs["o"] <= WAVE_TOL, (case, errs["o"])
+
+
+def test_live_caller_form_matches_reference_golden(net, golden_dir):
+    """The reference's ONE live call of infer (train.py:281, 300-301), argument for argument:
+    `infer(phonemes, phonemes_lengths, max_len=1000, sid=sid, pitch_control=shift, energy_control=energy_shift)` with
+    `shift, energy_shift = 1, 1` (Python ints), durations predicted (duration_control omitted), the default noise_scale
+    -- predicted durations + integer scalar controls + max_len in one call, on a ragged batch."""
+    g = golden(golden_dir, "evaluate_caller")
+    assert not g["in_use"].any() and int(g["in_max_len"]) == 1000 and float(g["in_noise_scale"]) == 1.0
+    t = lambda a: torch.from_numpy(np.asarray(a)).to(net.device)
+    shift, energy_shift = 1, 1
+    o, x_mask, (z, z_p, m_p, logs_p), duration, f0, energy = net.infer(
+        t(g["in_phonemes"]), t(g["in_lengths"]), max_len=1000, sid=t(g["in_sid"]), pitch_control=shift,
+        energy_control=energy_shift, noise=t(g["in_noise"]))
+    np.testing.assert_array_equal(to_np(duration).reshape(g["duration"].shape), g["duration"])      # predicted durations: exact
+    np.testing.assert_array_equal(to_np(x_mask), g["x_mask"])
+    # the reference's next line (train.py:302): y_hat_lengths = mask.sum([1, 2]).long() * hop_length
+    np.testing.assert_array_equal(to_np(x_mask.sum([1, 2]).long() * 512), g["x_mask"].sum((1, 2)) * 512)
+    for name, val in (("m_p", m_p), ("logs_p", logs_p), ("z_p", z_p), ("z", z), ("F0", f0), ("energy", energy)):
+        assert rel_err(to_np(val), g[name]) <= STAGE_TOL, name
+    assert o.shape == g["o"].shape and rel_err(to_np(o), g["o"]) <= WAVE_TOL
 
 
 @pytest.mark.parametrize("case", ["ragged_controls", "c1_filelist"])
@@ -364,8 +385,10 @@ def test_abi_error_paths_on_device(net):
         net.infer(torch.zeros(1, 3, dtype=torch.int64), torch.tensor([3]), sid=None)
     enc = eng.encode(torch.ones(1, 3, dtype=torch.int64), torch.tensor([3]), torch.tensor([1]),
                      duration_ctl=torch.ones(1, 3), pitch_ctl=torch.ones(1, 3), energy_ctl=torch.ones(1, 3))
-    with pytest.raises(ValueError):
-        eng.decode(enc, 3, None, 0.5, max_len=-1)          # the C side reads max_len < 0 as "no limit": refused here
+    with pytest.raises(ValueError, match="max_len"):
+        eng.decode(enc, 3, None, 0.5, max_len=-1, noise_seed=1)   # the C side reads max_len < 0 as "no limit": refused here
+    with pytest.raises(ValueError, match="noise_seed"):
+        eng.decode(enc, 3, None, 0.5)                      # no noise and no seed: refused (no silent seed 0)
     # vsp_attention: caller-owned workspace (ABI 4), too small -> error code
     qkv = torch.zeros(1, 3 * 192, 16, device=net.device)
     ln = torch.tensor([16], device=net.device)

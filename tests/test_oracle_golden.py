@@ -10,7 +10,7 @@ from oracle.vispeech_oracle import Oracle, rq_spline
 from vispeech_amd.schema import ModelDims
 from vispeech_amd.synth import synth_state_dict
 
-CASES = ["ragged_controls", "ragged_predictors", "maxlen_dur3d", "c1_filelist"]
+CASES = ["ragged_controls", "ragged_predictors", "maxlen_dur3d", "c1_filelist", "evaluate_caller"]
 
 
 @pytest.fixture(scope="module")

@@ -53,6 +53,10 @@ struct Run {
   hipStream_t s;
   Ws& ws;
   int rc = VSP_OK;
+  // ragged batch of the channels-last generator (kernels.h, ClConvArgs::glen): frames per utterance of the batch chunk
+  // being launched, and the columns per frame of the current stage's input / output tensors
+  const int* glen = nullptr;
+  int grate_in = 0, grate_out = 0;
   bool dry() const { return ws.dry; }
   const float* A(size_t off) const { return ctx->arena + off; }
   bool ok() const { return rc == VSP_OK && !ws.overflow; }
@@ -60,6 +64,11 @@ struct Run {
     if (e != hipSuccess && rc == VSP_OK) rc = ctx->fail(VSP_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
   }
 
+  static int fam(int kind, int channels) {
+    int l = 0;
+    while ((32 << l) < channels && l < 7) ++l;
+    return kind | (l << 3);
+  }
   ConvArgs args(const Conv& L, T3 x, T3 out, int T_in, int Nq) const {
     ConvArgs a;
     std::memset(&a, 0, sizeof a);
@@ -76,20 +85,28 @@ struct Run {
     return a;
   }
   // event pair around one launch of a profiled class; end() books the launch's algorithmic work
-  bool prof_begin(int cls) {
+  bool prof_begin(int cls, int fam = VSP_FAM_OTHER) {
     if (!ctx->prof_on) return false;
     while (ctx->ev_pool.size() < ctx->ev_used + 2) {
       hipEvent_t e;
       if (hipEventCreate(&e) != hipSuccess) { rc = ctx->fail(VSP_ERR_HIP, "hipEventCreate"); return false; }
       ctx->ev_pool.push_back(e);
     }
-    if (ctx->ev_cls.size() < ctx->ev_pool.size() / 2) ctx->ev_cls.resize(ctx->ev_pool.size() / 2, 0);
+    if (ctx->ev_cls.size() < ctx->ev_pool.size() / 2) {
+      ctx->ev_cls.resize(ctx->ev_pool.size() / 2, 0);
+      ctx->ev_fam.resize(ctx->ev_pool.size() / 2, 0);
+      ctx->ev_flops.resize(ctx->ev_pool.size() / 2, 0.0);
+      ctx->ev_bytes.resize(ctx->ev_pool.size() / 2, 0.0);
+    }
     ctx->ev_cls[ctx->ev_used / 2] = cls;
+    ctx->ev_fam[ctx->ev_used / 2] = fam;
     (void)hipEventRecord(ctx->ev_pool[ctx->ev_used], s);
     return true;
   }
   void prof_end(int cls, double flops, double bytes, double bytes_ext) {
     (void)hipEventRecord(ctx->ev_pool[ctx->ev_used + 1], s);
+    ctx->ev_flops[ctx->ev_used / 2] = flops;
+    ctx->ev_bytes[ctx->ev_used / 2] = bytes;
     ctx->ev_used += 2;
     ctx->prof_launches[cls] += 1;
     ctx->prof_flops[cls] += flops;
@@ -116,7 +133,8 @@ struct Run {
     a.acc_prev = acc_prev ? 1 : 0; a.div = div;
     a.terms = ctx->gen_mode == 2 ? 1 : 3;
     a.ring = ctx->chain_ring ? 1 : 0;
-    const bool prof = prof_begin(VSP_PROF_GENERATOR);
+    a.glen = glen; a.grate = grate_out;
+    const bool prof = prof_begin(VSP_PROF_GENERATOR, fam(VSP_FAM_CHAIN, ch));
     chk(launch_g16_chain(a, B, s), "g16_chain");
     if (prof) {
       // the 2 np convolutions this launch replaces, each charged its input and its output
@@ -128,7 +146,7 @@ struct Run {
   void conv(const ConvArgs& a, int B, bool generator = false) {
     if (dry() || !ok()) return;
     const int cls = generator ? VSP_PROF_GENERATOR : VSP_PROF_FRAME;
-    const bool prof = prof_begin(cls);
+    const bool prof = prof_begin(cls, generator ? (a.ups_s > 0 ? fam(VSP_FAM_UPS, a.M / a.ups_s) : fam(VSP_FAM_PRE, a.M)) : VSP_FAM_OTHER);
     chk(launch_conv(a, B, s), "conv1d_f32_mfma");
     if (prof) {
       const double in_el = (double)a.T_in * a.Cin, out_el = (double)(a.ups_s > 0 ? a.T_store * (a.M / a.ups_s) : a.Nq * a.M);
@@ -160,7 +178,8 @@ struct Run {
     a.acc_prev = acc_prev ? 1 : 0; a.div = div;
     a.phases = L.phases; a.ups_p = L.ups_p; a.T_store = T_store;
     a.terms = ctx->gen_mode == 2 ? 1 : 3;
-    const bool prof = prof_begin(VSP_PROF_GENERATOR);
+    a.glen = glen; a.g_in = L.phases > 1 ? grate_in : grate_out; a.g_store = grate_out;
+    const bool prof = prof_begin(VSP_PROF_GENERATOR, fam(L.phases > 1 ? VSP_FAM_UPS : VSP_FAM_CONV, L.Cout));
     chk(launch_g16_conv(a, B, s), "g16_conv");
     if (prof) {
       // input once + output once; the residual / accumulate reads go to bytes_ext
@@ -184,7 +203,8 @@ struct Run {
     a.acc_prev = acc_prev ? 1 : 0; a.div = div;
     a.terms = ctx->gen_mode == 2 ? 1 : 3;
     a.ring = ctx->pair_ring ? 1 : 0;
-    const bool prof = prof_begin(VSP_PROF_GENERATOR);
+    a.glen = glen; a.grate = grate_out;
+    const bool prof = prof_begin(VSP_PROF_GENERATOR, fam(VSP_FAM_PAIR, L1.Cout));
     chk(launch_g16_pair(a, B, s), "g16_pair");
     if (prof) {
       // the two convolutions this launch replaces: SURVEY.md 8d charges each its input and its output (4 passes of
@@ -454,8 +474,19 @@ void run_generator_cl(Run& r, int B, int T, T3 z, const int64_t* in_lengths, con
     }
   }
   uint16_t* timg = (r.ctx->t_img && mx_img && r.ctx->gen_mode == 1) ? reinterpret_cast<uint16_t*>(r.ws.f((size_t)B * mx_img)) : nullptr;
+  // Trimmed tails (round 5; VSP_TRIM_TAILS=0: off, second implementation, bit-identical).  Behind an utterance's last frame
+  // the input is exactly zero (z * x_mask, reference models.py:720), so the output there depends on the distance to the
+  // utterance's end and to the tensor's end only: every kernel below treats utterance b's tensor as ENDING after
+  // len_b + 2 halo + 1 frames (kernels.h, ClConvArgs::glen) -- frames [0, len + halo) come out as in the padded run, frame
+  // len + halo is the steady state (periodic in one frame), the last halo frames are the tensor end's -- and
+  // gen_tail_fill writes the rest of the padded tensor from those.  The reference's full padded output, bit for bit.
+  const int halo = vsp_generator_halo_frames(r.ctx);
+  int* glen_all = r.ctx->trim_tails ? reinterpret_cast<int*>(r.ws.bytes((size_t)B * sizeof(int))) : nullptr;
+  const bool trim = glen_all && in_lengths && T > 2 * halo + 1;
+  if (trim && !r.dry() && r.ok()) r.chk(launch_gen_plan(in_lengths, B, T, halo, glen_all, r.s), "gen_plan");
   // the channels-last kernels address one utterance's tensor with 32-bit byte offsets (buffer descriptors)
-  if (mx * sizeof(float) >= (size_t)1 << 31) {
+  // (the operand images -- C * 4 * (T + 384) bytes per utterance -- are addressed the same way)
+  if (mx * sizeof(float) >= (size_t)1 << 31 || (timg && mx_img * sizeof(float) >= (size_t)1 << 31)) {
     if (r.rc == VSP_OK)
       r.rc = r.ctx->fail(VSP_ERR_UNSUPPORTED, "generator: %d frames per call exceed the 2 GiB per-utterance activation "
                                               "limit; synthesise in chunks (Engine.generator_stream)", T);
@@ -494,12 +525,15 @@ void run_generator_cl(Run& r, int B, int T, T3 z, const int64_t* in_lengths, con
     }
     for (int b0 = 0; b0 < B; b0 += Bc) {
       const int nb = std::min(Bc, B - b0);
+      r.glen = trim ? glen_all + b0 : nullptr;
+      r.grate_in = (int)(Tn / T); r.grate_out = (int)(Tout / T);
       const float* xin = buf[cur] + (size_t)b0 * xbs;
       float *xu = XU + (size_t)b0 * bs, *t1 = T1 + (size_t)b0 * bs, *ya = YA + (size_t)b0 * bs, *xs = XS + (size_t)b0 * bs;
       r.clconv(U, xin, xbs, xu, bs, nullptr, 0, (int)Tn, (int)Tn + 1, (int)Tout, 0.1f, false, 1.f, nb);
       // stages that run one launch per convolution hand the pair's intermediate over as an operand image
       uint16_t* ti = (timg && ch >= 128 && ch % 32 == 0) ? timg + (size_t)b0 * cl_img_halfs(ch, (int)Tout) : nullptr;
-      if (ti && !r.dry() && r.ok()) r.chk(launch_cl_img_zero_pads(ti, nb, ch, (int)Tout, r.s), "cl_img_zero_pads");
+      if (ti && !r.dry() && r.ok())
+        r.chk(launch_cl_img_zero_pads(ti, nb, ch, (int)Tout, r.s, r.glen, r.grate_out), "cl_img_zero_pads");
       for (int j = 0; j < nk; ++j) {
         const ResBlockW& rb = m.rbs[i * nk + j];
         const int nd = (int)rb.dil.size();
@@ -541,9 +575,12 @@ void run_generator_cl(Run& r, int B, int T, T3 z, const int64_t* in_lengths, con
     cur = fb[3];
     Tn = Tout;
   }
-  if (!r.dry() && r.ok())
-    r.chk(launch_conv_post_cl(buf[cur], Tn * ch, ch, r.A(m.post_wt), m.post_c, m.post_k, 0.01f, o, Tn, B, (int)Tn, r.s),
-          "conv_post_cl");
+  r.glen = nullptr;
+  if (!r.dry() && r.ok()) {
+    r.chk(launch_conv_post_cl(buf[cur], Tn * ch, ch, r.A(m.post_wt), m.post_c, m.post_k, 0.01f, o, Tn, B, (int)Tn, r.s,
+                              trim ? glen_all : nullptr, (int)(Tn / T)), "conv_post_cl");
+    if (trim) r.chk(launch_gen_tail_fill(o, Tn, in_lengths, glen_all, B, T, halo, (int)(Tn / T), r.s), "gen_tail_fill");
+  }
 }
 
 void run_gen(Run& r, int B, int T, T3 z, const int64_t* in_lengths, const float* g, float* o) {
@@ -594,6 +631,7 @@ int vsp_create(const vsp_config* cfg, int device, vsp_ctx** out) {
   if (const char* e = getenv("VSP_PAIR")) ctx->pair_ring = !strcmp(e, "ring");
   if (const char* e = getenv("VSP_CHAIN_RING")) ctx->chain_ring = atoi(e) != 0;
   if (const char* e = getenv("VSP_CHAIN")) ctx->chain_mask = atoi(e);
+  if (const char* e = getenv("VSP_TRIM_TAILS")) ctx->trim_tails = atoi(e) != 0;   // 0: every utterance runs to the padded length
 #ifdef VSP_EXPERIMENTS
   if (const char* e = getenv("VSP_ATT_KSPLIT")) ctx->att_ksplit = atoi(e);
   if (const char* e = getenv("VSP_CHUNK_MB")) ctx->chunk_mb = atof(e);
@@ -1780,6 +1818,34 @@ int vsp_profile_read_class(vsp_ctx* ctx, int cls, int64_t* launches, double* tot
     if (!any) ctx->ev_used = 0;
   }
   return VSP_OK;
+}
+
+int vsp_profile_read_families(vsp_ctx* ctx, int cls, int max_families, int* family, int64_t* launches, double* total_ms,
+                              double* total_flops, double* total_bytes) {
+  if (!ctx || cls < 0 || cls >= VSP_PROF_CLASSES || max_families < 0 || !family || !launches || !total_ms || !total_flops ||
+      !total_bytes)
+    return ctx ? ctx->fail(VSP_ERR_ARG, "vsp_profile_read_families: bad argument") : VSP_ERR_ARG;
+  int n = 0;
+  for (size_t i = 0; i + 1 < ctx->ev_used; i += 2) {
+    if (ctx->ev_cls[i / 2] != cls) continue;
+    hipError_t e = hipEventSynchronize(ctx->ev_pool[i + 1]);
+    float t = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&t, ctx->ev_pool[i], ctx->ev_pool[i + 1]);
+    if (e != hipSuccess) return ctx->fail(VSP_ERR_HIP, "profile events: %s", hipGetErrorString(e));
+    const int f = ctx->ev_fam[i / 2];
+    int k = 0;
+    while (k < n && family[k] != f) ++k;
+    if (k == n) {
+      if (n == max_families) continue;
+      family[n] = f; launches[n] = 0; total_ms[n] = total_flops[n] = total_bytes[n] = 0.0;
+      ++n;
+    }
+    launches[k] += 1;
+    total_ms[k] += t;
+    total_flops[k] += ctx->ev_flops[i / 2];
+    total_bytes[k] += ctx->ev_bytes[i / 2];
+  }
+  return n;
 }
 
 int vsp_profile_read(vsp_ctx* ctx, int64_t* launches, double* total_ms, double* total_flops, double* total_bytes,

@@ -43,11 +43,16 @@ constexpr int CPL_TILE = 256;
 template <int C>
 __global__ void __launch_bounds__(256) conv_post_cl_kernel(const float* __restrict__ x, long x_bs,
                                                            const float* __restrict__ wt /* [K][C] */, int K,
-                                                           float slope, float* __restrict__ o, long o_bs, int T) {
+                                                           float slope, float* __restrict__ o, long o_bs, int T,
+                                                           const int* __restrict__ glen, int grate) {
   constexpr int RSF = C + 4;
   constexpr int C4 = C / 4;
   __shared__ __attribute__((aligned(16))) float xs[(CPL_TILE + 8) * RSF];
   const int b = blockIdx.y, t0 = blockIdx.x * CPL_TILE, pad = (K - 1) / 2;
+  if (glen) {                                   // ragged batch: this utterance's tensor ends at glen[b] * grate
+    T = __builtin_amdgcn_readfirstlane(glen[b]) * grate;
+    if (t0 >= T) return;
+  }
   const int rows = CPL_TILE + K - 1;
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x) + (size_t)b * x_bs, 0,
                                                                       T * C * 4, 0x00020000);
@@ -78,13 +83,13 @@ __global__ void __launch_bounds__(256) conv_post_cl_kernel(const float* __restri
   if (t < T) o[(size_t)b * o_bs + t] = tanhf(acc);
 }
 hipError_t launch_conv_post_cl(const float* x, long x_bs, int x_ts, const float* w, int C, int K, float slope,
-                               float* o, long o_bs, int B, int T, hipStream_t s) {
+                               float* o, long o_bs, int B, int T, hipStream_t s, const int* glen, int grate) {
   if (K > 8 || x_ts != C || (C != 32 && C != 64)) return hipErrorInvalidValue;
   dim3 grid((T + CPL_TILE - 1) / CPL_TILE, B);
   if (C == 32)
-    hipLaunchKernelGGL(conv_post_cl_kernel<32>, grid, dim3(256), 0, s, x, x_bs, w, K, slope, o, o_bs, T);
+    hipLaunchKernelGGL(conv_post_cl_kernel<32>, grid, dim3(256), 0, s, x, x_bs, w, K, slope, o, o_bs, T, glen, grate);
   else
-    hipLaunchKernelGGL(conv_post_cl_kernel<64>, grid, dim3(256), 0, s, x, x_bs, w, K, slope, o, o_bs, T);
+    hipLaunchKernelGGL(conv_post_cl_kernel<64>, grid, dim3(256), 0, s, x, x_bs, w, K, slope, o, o_bs, T, glen, grate);
   return hipGetLastError();
 }
 
@@ -92,17 +97,70 @@ hipError_t launch_conv_post_cl(const float* x, long x_bs, int x_ts, const float*
 // Operand images (kernels.h ClConvArgs::x_img / o_img): the producer writes the data rows [PADF, PADF + T) of every
 // plane; the CL_IMG_PADF rows in front and the CL_IMG_PADB rows behind must read as zero (the convolution's zero padding
 // and the last tile's overshoot).  One block per plane: planes = B * (C / 32) * 2 * 4.
-__global__ void __launch_bounds__(256) cl_img_zero_pads_kernel(uint4* __restrict__ img, int T, int tpad) {
+// Ragged batch: utterance b's data rows end at glen[b] * grate; its CL_IMG_PADB zero rows sit right behind them (the
+// rows further back are never read: a tile behind the utterance's end does not run).
+__global__ void __launch_bounds__(256) cl_img_zero_pads_kernel(uint4* __restrict__ img, int T, int tpad, int planes_per_utt,
+                                                               const int* __restrict__ glen, int grate) {
   uint4* pl = img + (size_t)blockIdx.x * tpad;
   const uint4 z = {0u, 0u, 0u, 0u};
+  int end = tpad;
+  if (glen) {
+    T = glen[blockIdx.x / planes_per_utt] * grate;
+    end = CL_IMG_PADF + T + CL_IMG_PADB;
+  }
   for (int r = threadIdx.x; r < CL_IMG_PADF; r += 256) pl[r] = z;
-  for (int r = CL_IMG_PADF + T + threadIdx.x; r < tpad; r += 256) pl[r] = z;
+  for (int r = CL_IMG_PADF + T + threadIdx.x; r < end; r += 256) pl[r] = z;
 }
-hipError_t launch_cl_img_zero_pads(uint16_t* img, int B, int C, int T, hipStream_t s) {
+hipError_t launch_cl_img_zero_pads(uint16_t* img, int B, int C, int T, hipStream_t s, const int* glen, int grate) {
   if (B <= 0 || C % 32 || T <= 0 || (reinterpret_cast<uintptr_t>(img) & 15)) return hipErrorInvalidValue;
-  const long planes = (long)B * (C / 32) * 8;
+  const int ppu = (C / 32) * 8;
+  const long planes = (long)B * ppu;
   hipLaunchKernelGGL(cl_img_zero_pads_kernel, dim3((unsigned)planes), dim3(256), 0, s, reinterpret_cast<uint4*>(img), T,
-                     cl_img_tpad(T));
+                     cl_img_tpad(T), ppu, glen, grate);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Trimmed tails (kernels.h).  gen_plan: the frames the generator computes per utterance.
+__global__ void gen_plan_kernel(const int64_t* __restrict__ lengths, int B, int T, int halo, int* __restrict__ glen) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  long len = lengths[b];
+  len = len < 0 ? 0 : len;
+  const long e = len + 2 * halo + 1;
+  glen[b] = e < T ? (int)e : T;
+}
+hipError_t launch_gen_plan(const int64_t* lengths, int B, int T, int halo, int* glen, hipStream_t s) {
+  if (!lengths || !glen || B <= 0 || T <= 0 || halo < 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gen_plan_kernel, dim3((B + 63) / 64), dim3(64), 0, s, lengths, B, T, halo, glen);
+  return hipGetLastError();
+}
+// gen_tail_fill: one block per utterance.  The computed tensor end -- frames [len + halo + 1, len + 2 halo + 1) -- is read
+// into LDS first (the steady-state fill overwrites it), then frames [len + halo + 1, T - halo) get the steady-state frame
+// len + halo and frames [T - halo, T) the saved tensor end.  Utterances the plan did not trim (glen[b] == T) are skipped.
+__global__ void __launch_bounds__(1024) gen_tail_fill_kernel(float* __restrict__ o, long o_bs, const int64_t* __restrict__ lengths,
+                                                             const int* __restrict__ glen, int T, int halo, int up) {
+  extern __shared__ float tail[];                 // [halo * up]
+  const int b = blockIdx.x;
+  if (glen[b] >= T) return;
+  long len = lengths[b];
+  len = len < 0 ? 0 : len;
+  float* ob = o + (size_t)b * o_bs;
+  const long s0 = (len + halo) * up;              // the steady-state frame
+  const long e0 = s0 + up;                        // the computed tensor end: halo frames from here
+  const int nt = halo * up;
+  for (int i = threadIdx.x; i < nt; i += blockDim.x) tail[i] = ob[e0 + i];
+  __syncthreads();
+  const long fill_end = (long)(T - halo) * up;
+  for (long i = e0 + threadIdx.x; i < fill_end; i += blockDim.x) ob[i] = ob[s0 + (i - e0) % up];
+  for (int i = threadIdx.x; i < nt; i += blockDim.x) ob[fill_end + i] = tail[i];
+}
+hipError_t launch_gen_tail_fill(float* o, long o_bs, const int64_t* lengths, const int* glen, int B, int T, int halo, int up,
+                                hipStream_t s) {
+  if (!o || !lengths || !glen || B <= 0 || T <= 0 || halo < 0 || up <= 0) return hipErrorInvalidValue;
+  const size_t lds = (size_t)halo * up * sizeof(float);
+  if (lds > 64 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gen_tail_fill_kernel, dim3(B), dim3(1024), lds, s, o, o_bs, lengths, glen, T, halo, up);
   return hipGetLastError();
 }
 

@@ -173,6 +173,32 @@ __device__ __forceinline__ void g16_div(f32x4& v, float div) {
     v /= div;
   }
 }
+// Ragged batches (round 5): the time extent of utterance b in a launch whose uniform extent is T (kernels.h, ClConvArgs)
+__device__ __forceinline__ int g16_len(const int* glen, int b, int grate, int T) {
+  return glen ? __builtin_amdgcn_readfirstlane(glen[b]) * grate : T;
+}
+// A persistent block's run of tiles in the (utterance, tile) sequence of a ragged batch: utterance b has
+// ceil(len_b / R) tiles.  Returns the run's first tile as (b0, tile0 within b0) and its length n.  Prologue code: plain
+// scalar loads and divisions, once per block.
+__device__ __forceinline__ void g16_ragged_run(const int* glen, int B, int grate, int R, int nblocks, int bid, int& b0,
+                                               int& tile0, int& n) {
+  int total = 0;
+  for (int b = 0; b < B; ++b) total += (glen[b] * grate + R - 1) / R;
+  const int per = total / nblocks, extra = total - per * nblocks;
+  const int lo = bid * per + (bid < extra ? bid : extra);
+  n = per + (bid < extra ? 1 : 0);
+  int acc = 0, b = 0;
+  for (; b < B - 1; ++b) {
+    const int nt = (glen[b] * grate + R - 1) / R;
+    if (lo < acc + nt) break;
+    acc += nt;
+  }
+  // (loads through a plain global pointer are vector loads: the results are uniform but the compiler does not know it)
+  b0 = __builtin_amdgcn_readfirstlane(b);
+  tile0 = __builtin_amdgcn_readfirstlane(lo - acc);
+  n = __builtin_amdgcn_readfirstlane(n);
+}
+
 __device__ __forceinline__ f32x4 g16_as_f32x4(const u32x4 v) {
   return f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
 }

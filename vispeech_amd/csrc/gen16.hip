@@ -114,6 +114,13 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
   const int id = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (orig >> 3);
   const int cb = id % gy, bx = (id / gy) % gx, b = id / (gy * gx);
   const int t0 = bx * BT;
+  // ragged batch: this utterance's own extents (kernels.h); a tile behind its end has nothing to do
+  int T_in = a.T_in, Nq = a.Nq, T_store = a.T_store;
+  if (a.glen) {
+    const int gl = __builtin_amdgcn_readfirstlane(a.glen[b]);
+    T_in = gl * a.g_in; Nq = T_in + (a.Nq - a.T_in); T_store = gl * a.g_store;
+    if (t0 >= Nq) return;
+  }
   const int K = a.K, S = nch * K;
   const int xrows = BT + (K - 1) * a.dil;        // window rows actually needed
 #ifdef G16_STAMPS
@@ -129,12 +136,12 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
 #endif
 
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.x) + (size_t)b * a.x_bs, 0, a.T_in * a.x_ts * 4, 0x00020000);
+      const_cast<float*>(a.x) + (size_t)b * a.x_bs, 0, T_in * a.x_ts * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
-      g16_out_base(a, b), 0, a.out ? a.T_store * a.o_ts * 4 : 0, 0x00020000);
+      g16_out_base(a, b), 0, a.out ? T_store * a.o_ts * 4 : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rr_ = __builtin_amdgcn_make_buffer_rsrc(
       a.res ? const_cast<float*>(a.res) + (size_t)b * a.r_bs : g16_out_base(a, b), 0,
-      a.res ? a.T_store * a.r_ts * 4 : (a.out ? a.T_store * a.o_ts * 4 : 0), 0x00020000);
+      a.res ? T_store * a.r_ts * 4 : (a.out ? T_store * a.o_ts * 4 : 0), 0x00020000);
 
   // ---- window staging: 16 consecutive lanes write 128 contiguous bytes of one plane (conflict-free)
   const int g16 = tid >> 4, kq_s = g16 & 3, row_s = (g16 >> 2) * 8 + ((tid >> 1) & 7), half_s = tid & 1;
@@ -332,7 +339,7 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
     for (int j = 0; j < NW; ++j) {
       const int t = t0 + (wn * NW + j) * 16 + (lane & 15);
       const int n = a.phases * t + ph - a.ups_p;            // output row (< 0 or >= T_store: dropped by the descriptor)
-      const bool in_t = t < a.Nq && (G16_DIAG & 8) == 0;
+      const bool in_t = t < Nq && (G16_DIAG & 8) == 0;
       oo[i][j] = in_t ? n * a.o_ts * 4 + co * 4 : G16_OOR;
       orr[i][j] = in_t ? n * a.r_ts * 4 + co * 4 : G16_OOR;
     }
@@ -383,7 +390,7 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
           const int unit = ((((co >> 5) * 2) * 4 + ((co & 31) >> 3)) * a.oi_tpad + G16_IMG_PADF + t) * 16 + 2 * (co & 7);
           f16x4 eh, el;
           g16_split4(v, a.oi_slope, true, eh, el);
-          const int off = t < a.Nq ? unit : G16_OOR;
+          const int off = t < Nq ? unit : G16_OOR;
           __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, eh), ri, off, 0, 0);
           __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, el), ri, off, 4 * a.oi_tpad * 16, 0);
         }
@@ -463,7 +470,12 @@ __global__ void __launch_bounds__(64 * (ROLES > 4 ? ROLES : 4)) g16_ups(ClConvAr
   const int role = wave % ROLES, stream = wave / ROLES;
   const int b = blockIdx.y;
   const int nmt_all = a.phases * a.Cout / 16, mt0 = role * NMT;
-  const int ntiles = (a.Nq + 15) / 16;
+  int T_in = a.T_in, Nq = a.Nq, T_store = a.T_store;            // (ragged batch: this utterance's own extents, kernels.h)
+  if (a.glen) {
+    const int gl = __builtin_amdgcn_readfirstlane(a.glen[b]);
+    T_in = gl * a.g_in; Nq = T_in + (a.Nq - a.T_in); T_store = gl * a.g_store;
+  }
+  const int ntiles = (Nq + 15) / 16;
   const int run = blockIdx.x * (NWB / ROLES) + stream;
   const int tile_lo = run * tiles_per_wave;
   const int tile_hi = tile_lo + tiles_per_wave < ntiles ? tile_lo + tiles_per_wave : ntiles;
@@ -505,7 +517,7 @@ __global__ void __launch_bounds__(64 * (ROLES > 4 ? ROLES : 4)) g16_ups(ClConvAr
 #pragma unroll
     for (int tap = 0; tap < KT; ++tap) {
       const int xr = q0 + l15 - (KT - 1) + tap;
-      const bool ok = xr >= 0 && xr < a.T_in;
+      const bool ok = xr >= 0 && xr < T_in;
       const float* p = xb + (size_t)(ok ? xr : 0) * a.x_ts;
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
@@ -539,7 +551,7 @@ __global__ void __launch_bounds__(64 * (ROLES > 4 ? ROLES : 4)) g16_ups(ClConvAr
       for (int jj = 0; jj < 4; ++jj) {
         const int q = q0 + 4 * kg + jj;
         const int n = a.phases * q + ph_of[m] - a.ups_p;
-        if (q < a.Nq && n >= 0 && n < a.T_store)
+        if (q < Nq && n >= 0 && n < T_store)
           ob[(size_t)n * a.o_ts + co_of[m]] = hh[m][jj] + cr[m][jj] * (1.f / 2048.f) + bv[m];
       }
   }
@@ -562,6 +574,11 @@ hipError_t launch_g16_conv(const ClConvArgs& a, int B, hipStream_t s) {
     return hipErrorInvalidValue;
   if ((a.x_img || a.o_img) && (a.terms != 3 || a.phases != 1)) return hipErrorInvalidValue;
   if (a.o_img && (a.oi_tpad < cl_img_tpad(a.T_store) || (a.oi_bs & 7) || (reinterpret_cast<uintptr_t>(a.o_img) & 15)))
+    return hipErrorInvalidValue;
+  // an utterance's operand image is addressed with 32-bit byte offsets (descriptor num_records, `unit` in the epilogue);
+  // the image-input windows are raw pointer reads of rows [t0 - pad, t0 + BT + halo): only the pad rows cover an overshoot
+  if ((a.o_img && (size_t)a.Cout * 4 * (size_t)a.oi_tpad >= (size_t)1 << 31) ||
+      (a.x_img && ((size_t)a.Cin * 4 * (size_t)a.xi_tpad >= (size_t)1 << 31 || a.Nq > a.T_in)))
     return hipErrorInvalidValue;
   const int rows = a.phases * a.Cout;
   // the short up-convs (kernel 4 at stride 4 or 2): streaming kernel (no residual / accumulate operands there)
@@ -595,7 +612,7 @@ hipError_t launch_g16_conv(const ClConvArgs& a, int B, hipStream_t s) {
   if (a.x_img) {                                                                        // input = operand image (LDS-DMA windows)
     if (a.K < 3 || a.phases != 1 || a.pad > CL_IMG_PADF || a.xi_tpad < cl_img_tpad(a.T_in) || (a.xi_bs & 7)) return hipErrorInvalidValue;
     if (rows % 128 == 0 && want >= 128) {
-      if (g16_pipe_supported(a)) return launch_g16_pipe(a, B, s);                        // persistent, pipelined across tiles
+      if (!a.glen && g16_pipe_supported(a)) return launch_g16_pipe(a, B, s);             // persistent, pipelined across tiles (uniform batches)
       return launch_g16_tile<4, 4, 2, 4, 3, true>(a, B, s);
     }
     if (rows % 64 == 0 && want >= 64) return launch_g16_tile<4, 2, 1, 8, 3, true>(a, B, s);
@@ -664,13 +681,15 @@ __global__ void __launch_bounds__(64 * NWV, 4) g16_pair(ClPairArgs a) {
   const int K = a.K, p2 = (K - 1) >> 1, p1 = a.dil * p2;
   const int R2 = BT - (K - 1);                  // output columns per block
   const int t0 = tile * R2;                     // first output column
+  const int T = g16_len(a.glen, b, a.grate, a.T);   // (ragged batch: this utterance's own extent)
+  if (t0 >= T) return;
   const int ns = (K + G - 1) / G;               // slices per chunk
   const int S1 = NCH * ns, S = 2 * S1;
   const int xrows = BT + (K - 1) * a.dil;
 
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.x) + (size_t)b * a.x_bs, 0, a.T * C * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)b * a.o_bs, 0, a.T * C * 4,
+      const_cast<float*>(a.x) + (size_t)b * a.x_bs, 0, T * C * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)b * a.o_bs, 0, T * C * 4,
                                                                       0x00020000);
 
   // ---- x window staging (as in g16_conv): row 0 of the window is time t0 - p2 - p1
@@ -836,7 +855,7 @@ __global__ void __launch_bounds__(64 * NWV, 4) g16_pair(ClPairArgs a) {
 #pragma unroll
   for (int j = 0; j < NW; ++j) {
     const int tt = t0 - p2 + wave * 32 + 16 * j + l15;
-    const bool valid = tt >= 0 && tt < a.T;
+    const bool valid = tt >= 0 && tt < T;
 #pragma unroll
     for (int i = 0; i < MW; ++i) {
       f32x4 v;
@@ -1019,12 +1038,14 @@ __global__ void __launch_bounds__(64 * NWV, 2) g16_chain(ClChainArgs a) {
   const int K = a.K, p2 = (K - 1) >> 1, H = a.halo;
   const int R = BT - 2 * H;                     // columns stored per block
   const int tb = tile * R - H;                  // time of column 0
+  const int T = g16_len(a.glen, b, a.grate, a.T);   // (ragged batch: this utterance's own extent)
+  if (tile * R >= T) return;
   const int ns = (K + G - 1) / G;               // slices per chunk
   const int S = 2 * a.np * NCH * ns;
 
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.x) + (size_t)b * a.x_bs, 0, a.T * C * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)b * a.o_bs, 0, a.T * C * 4,
+      const_cast<float*>(a.x) + (size_t)b * a.x_bs, 0, T * C * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)b * a.o_bs, 0, T * C * 4,
                                                                       0x00020000);
   const float slope = a.slope;
 
@@ -1034,7 +1055,7 @@ __global__ void __launch_bounds__(64 * NWV, 2) g16_chain(ClChainArgs a) {
 #pragma unroll
   for (int j = 0; j < NW; ++j) {
     const int t = tb + wave * CW + 16 * j + l15;
-    tval[j] = t >= 0 && t < a.T;
+    tval[j] = t >= 0 && t < T;
 #pragma unroll
     for (int i = 0; i < MW; ++i)
       xr[i][j] = (G16_DIAG & 16) ? f32x4{1.f, 2.f, 3.f, 4.f}
@@ -1232,7 +1253,7 @@ __global__ void __launch_bounds__(64 * NWV, 2) g16_chain(ClChainArgs a) {
     for (int j = 0; j < NW; ++j) {
       const int col = wave * CW + 16 * j + l15;
       const int t = tb + col;
-      const int off = (col >= H && col < H + R && t < a.T) ? (t * C + 16 * i + 4 * q4) * 4 : G16_OOR;
+      const int off = (col >= H && col < H + R && t < T) ? (t * C + 16 * i + 4 * q4) * 4 : G16_OOR;
       f32x4 v = result(i, j);
       v += xr[i][j];
       if (a.acc_prev) v += g16_as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(ro, off, 0, 0));

@@ -291,7 +291,9 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_convp(ClConvArgs a) {
           else if (behind == 1) g16_vm_wait<NBW, NL>(true, xl_a + xl_b);
           else g16_vm_wait<2 * NBW, NL>(true, xl_a + xl_b);
         } else if (!res_type) {
-          g16_vmcnt_rt(behind * my_pieces + (xl_a + xl_b) * NL + epi_stores);
+          // (+ MW * NW: the epilogue's residual-operand loads are issued unconditionally -- on the empty descriptor here --
+          // and sit in the same queue, younger than the slice waited for)
+          g16_vmcnt_rt(behind * my_pieces + (xl_a + xl_b) * NL + epi_stores + MW * NW);
         }
         // (else: the epilogue waited vmcnt(0) for its operands: every slice requested before it has landed)
       }

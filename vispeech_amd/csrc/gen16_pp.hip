@@ -96,12 +96,14 @@ __global__ void __launch_bounds__(512) g16_pp(ClPairArgs a) {
   const int K = a.K, p2 = (K - 1) >> 1, p1 = a.dil * p2;
   const int R2 = BT - (K - 1);                  // output columns per block
   const int t0 = tile * R2;                     // first output column
+  const int T = g16_len(a.glen, b, a.grate, a.T);   // (ragged batch: this utterance's own extent)
+  if (t0 >= T) return;
   const int S1 = NCH * K, S = 2 * S1;
   const int xrows = BT + (K - 1) * a.dil;       // window rows conv1 reads
 
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.x) + (size_t)b * a.x_bs, 0, a.T * C * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)b * a.o_bs, 0, a.T * C * 4,
+      const_cast<float*>(a.x) + (size_t)b * a.x_bs, 0, T * C * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)b * a.o_bs, 0, T * C * 4,
                                                                       0x00020000);
 
   // ---- x window staging: row 0 of the window is time t0 - p2 - p1; 16 consecutive lanes write 128 contiguous bytes of
@@ -274,7 +276,7 @@ __global__ void __launch_bounds__(512) g16_pp(ClPairArgs a) {
   for (int j = 0; j < NW; ++j) {
     const int row = wn * NW * 16 + 16 * j + l15;
     const int tt = t0 - p2 + row;
-    const bool valid = tt >= 0 && tt < a.T;
+    const bool valid = tt >= 0 && tt < T;
 #pragma unroll
     for (int i = 0; i < MW; ++i) {
       f32x4 v = hh[i][j] + cr[i][j] * (1.f / 2048.f);
@@ -365,8 +367,11 @@ static hipError_t launch_g16_pp_tile(ClPairArgs a, int B, hipStream_t s) {
   a.tiles = (a.T + R2 - 1) / R2;
   const long n = (long)a.tiles * B;
   if (n <= 0 || n > 0x7fffffffL) return hipErrorInvalidValue;
+  // (timing-only ablations, results WRONG by construction: experiment builds only)
+#ifdef VSP_EXPERIMENTS
   static const int diag = []() { const char* e = getenv("VSP_PP_DIAG"); return e ? atoi(e) : 0; }();
   a.terms |= diag << 8;
+#endif
   hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(512), lds, s, a);
   return hipGetLastError();
 }

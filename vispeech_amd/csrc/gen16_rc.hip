@@ -59,11 +59,20 @@ __global__ void __launch_bounds__(512) g16_rc(ClChainArgs a, int total_tiles) {
   const bool is1 = wave < 4;               // conv1 waves 0-3, conv2 waves 4-7 (w and w + 4 share a SIMD)
   const int wr = wave & 3;
 
-  // this block's run of tiles in the (utterance, tile) sequence
+  // this block's run of tiles in the (utterance, tile) sequence; ragged batch (ClChainArgs::glen): utterance b has
+  // ceil(glen[b] * grate / R) tiles instead of a.tiles
   const int nb = gridDim.x, bid = blockIdx.x;
-  const int per = total_tiles / nb, extra = total_tiles - per * nb;
-  const int lo = bid * per + (bid < extra ? bid : extra), n = per + (bid < extra ? 1 : 0);
   const int H = a.halo, R = RC_BT - 2 * H;
+  int lo_b, lo_tile, n;
+  if (a.glen) {
+    g16_ragged_run(a.glen, a.B, a.grate, R, nb, bid, lo_b, lo_tile, n);
+  } else {
+    const int per = total_tiles / nb, extra = total_tiles - per * nb;
+    const int lo = bid * per + (bid < extra ? bid : extra);
+    n = per + (bid < extra ? 1 : 0);
+    lo_b = lo / a.tiles;
+    lo_tile = lo - lo_b * a.tiles;
+  }
 
   // ---- the role's weights: A fragments of the three pairs' packed images [tap][m-tile][hi | lo][lane][8 halfs]
   f16x8 Wh[RC_NP][K][2], Wl[RC_NP][K][2];
@@ -142,24 +151,47 @@ __global__ void __launch_bounds__(512) g16_rc(ClChainArgs a, int total_tiles) {
     if constexpr (RC_PRIO) __builtin_amdgcn_s_setprio(0);
   };
 
-  // ---- tiles: (b, tile) of the run's m-th tile; tb = time of its column 0
-  struct TileAt { int b, tb; };
-  auto tile_at = [&](int m) -> TileAt {
-    const int id = lo + m, b = id / a.tiles;
-    return TileAt{b, (id - b * a.tiles) * R - H};
+  // ---- tiles: the run's tiles m - 1 and m as carried cursors (utterance, time of column 0, the utterance's extent); tiles
+  //      m + 1 / m + 2 are stepped from tile m where the staging needs them (scalar adds and compares)
+  // (utterance | extent << 8 in ONE scalar -- B <= 256 per launch, T < 2^24 --: a cursor is two scalar registers)
+  struct TileAt {
+    int tb; unsigned bT;
+    __device__ int b() const { return (int)(bT & 255u); }
+    __device__ int T() const { return (int)(bT >> 8); }
+  };
+  // (the ragged-batch parameters are re-read from the kernel-argument segment in the rare branch that needs them: kept
+  // in scalar registers across the persistent loop they push other scalars into vector lanes -- the trick of g16_convp)
+  auto T_of = [&](int b) -> int {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) ClChainArgs* KArgs;
+    KArgs ea = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ea));                             // (opaque: not hoisted out of the branch, not kept live)
+    const int* gl = ea->glen;
+    if (!gl) return ea->T;
+    const int nB = ea->B;
+    return __builtin_amdgcn_readfirstlane(gl[b < nB ? b : nB - 1]) * ea->grate;   // (a cursor may step past the last utterance: never used then)
+#else
+    return 0;
+#endif
+  };
+  auto tile_step = [&](TileAt t) -> TileAt {
+    t.tb += R;
+    if (t.tb + H >= t.T()) { t.tb = -H; const int nb_ = t.b() + 1; t.bT = (unsigned)(nb_ & 255) | ((unsigned)T_of(nb_) << 8); }
+    return t;
   };
   // ---- the fp32 window of a tile: rows [tb - GRD, tb + BT + GRD) by LDS-DMA into the staging area (wave w: the 1 KiB
   //      pieces w, w + 8, w + 16, w + 24 of 8 rows each), split into its pass-0 x image by the wave that requested them.
   //      Rows outside the utterance are fetched from a clamped address and zeroed at the split (the reference's padding).
   auto dma_window = [&](TileAt at, int ln) {
-    const char* xb = reinterpret_cast<const char*>(a.x + (size_t)at.b * a.x_bs);
+    const char* xb = reinterpret_cast<const char*>(a.x + (size_t)at.b() * a.x_bs);
     const int t00 = at.tb - RC_GRD;
+    const int Tu = at.T();
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int p = wave + 8 * u;
       if (8 * p < RC_WR) {
         int t = t00 + 8 * p + (ln >> 3);
-        t = t < 0 ? 0 : (t >= a.T ? a.T - 1 : t);
+        t = t < 0 ? 0 : (t >= Tu ? Tu - 1 : t);
         const char* gp = xb + ((unsigned)t * 128u + (unsigned)(ln & 7) * 16u);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
                                          (__attribute__((address_space(3))) void*)(STG + p * 1024), 16, 0, 0);
@@ -169,6 +201,7 @@ __global__ void __launch_bounds__(512) g16_rc(ClChainArgs a, int total_tiles) {
   };
   auto split_window = [&](TileAt at, int buf, int ln) {      // (the caller has waited for this wave's pieces)
     const int t00 = at.tb - RC_GRD;
+    const int Tu = at.T();
     char* const xw = XW + buf * RC_BUF;
     const int kq = ln & 3;
 #pragma unroll
@@ -179,7 +212,7 @@ __global__ void __launch_bounds__(512) g16_rc(ClChainArgs a, int total_tiles) {
         const char* sp = STG + r * 128 + kq * 32;
         f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 16);
         const int t = t00 + r;
-        if (t < 0 || t >= a.T) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
+        if (t < 0 || t >= Tu) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
         f16x4 h0, l0, h1, l1;
         g16_split4(v0, slope, true, h0, l0);
         g16_split4(v1, slope, true, h1, l1);
@@ -193,9 +226,9 @@ __global__ void __launch_bounds__(512) g16_rc(ClChainArgs a, int total_tiles) {
   // an activated, split D-layout tile pair (channels 4 q4 .. + 3 and 16 + 4 q4 .. + 3 of column `col`) -> image; columns
   // outside the utterance are the next convolution's zero padding.  A lane's four channels 16 i + 4 q4 .. + 3 sit in plane
   // 2 i + (q4 >> 1) at byte 8 (q4 & 1) of the row's 16
-  auto write_image = [&](auto MASK, char* img, int col, int q4, int t, f32x4 v0, f32x4 v1) {
+  auto write_image = [&](auto MASK, char* img, int col, int q4, int t, int T, f32x4 v0, f32x4 v1) {
     if constexpr (decltype(MASK)::value) {
-      if (!(t >= 0 && t < a.T)) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
+      if (!(t >= 0 && t < T)) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
     }
     f16x4 eh, el;
     char* dst = img + (q4 >> 1) * RC_PL + (RC_GRD + col) * 16 + 8 * (q4 & 1);
@@ -208,11 +241,15 @@ __global__ void __launch_bounds__(512) g16_rc(ClChainArgs a, int total_tiles) {
   };
 
   // ================= prologue: tile 0's window split, tile 1's requested =================
+  TileAt tq, tc;                                             // tiles m - 1, m
+  tc.tb = lo_tile * R - H;
+  tc.bT = (unsigned)(lo_b & 255) | ((unsigned)T_of(lo_b) << 8);
+  tq = tc;
   if (n > 0) {
-    dma_window(tile_at(0), lane);
+    dma_window(tc, lane);
     g16_vmcnt<0>();
-    split_window(tile_at(0), 0, lane);
-    if (n > 1) dma_window(tile_at(1), lane);
+    split_window(tc, 0, lane);
+    if (n > 1) dma_window(tile_step(tc), lane);
   }
   G16_BARRIER();
 
@@ -220,10 +257,14 @@ __global__ void __launch_bounds__(512) g16_rc(ClChainArgs a, int total_tiles) {
   f32x4 xa[RC_G][2], xb[RC_G][2];          // xa: the tile of this body's passes 0 / 1 (tile m); xb: tile m - 1
 
   // one ITEM of a role: (tile m, pass P) at iteration j -- conv1 waves run item (j), conv2 waves item (j - 1)
-  auto conv1_item_m = [&](auto P, auto MASK, int m, int j, int ln) {
+  // (the tile passes through an asm statement at the top of an item: as values of the enclosing body, live across the
+  // uniform branch between the two instantiations, the cursor's scalars cost the register allocator 20 spilled VECTOR
+  // registers -- weights reloaded from scratch inside the MFMA clusters)
+  auto conv1_item_m = [&](auto P, auto MASK, TileAt at, int m, int j, int ln) {
     constexpr int p = decltype(P)::value;
     const int q4 = ln >> 4, l15 = ln & 15;
-    const TileAt at = tile_at(m);
+    asm volatile("" : "+s"(at.tb), "+s"(at.bT));
+    const int Tu = at.T();
     const int d = a.dil[p];
     const unsigned xb0 = lds0 + (m & 1) * RC_BUF + q4 * RC_PL + (RC_GRD + wr * RC_CW + l15 - d) * 16;
     const unsigned bias_a = lds0 + RC_BIAS + (2 * p) * 128 + q4 * 16;
@@ -236,24 +277,25 @@ __global__ void __launch_bounds__(512) g16_rc(ClChainArgs a, int total_tiles) {
                  hh0, hh1, cr0, cr1);
       const int col = wr * RC_CW + 16 * g + l15;
       const int t = at.tb + col;
-      write_image(MASK, ti, col, q4, t, hh0 + cr0 * (1.f / 2048.f), hh1 + cr1 * (1.f / 2048.f));
+      write_image(MASK, ti, col, q4, t, Tu, hh0 + cr0 * (1.f / 2048.f), hh1 + cr1 * (1.f / 2048.f));
     });
   };
-  auto conv2_item_m = [&](auto P, auto MASK, int m, int j, int ln, f32x4 (&xr)[RC_G][2]) {
+  auto conv2_item_m = [&](auto P, auto MASK, TileAt at, int m, int j, int ln, f32x4 (&xr)[RC_G][2]) {
     constexpr int p = decltype(P)::value;
     const int q4 = ln >> 4, l15 = ln & 15;
-    const TileAt at = tile_at(m);
+    asm volatile("" : "+s"(at.tb), "+s"(at.bT));
+    const int Tu = at.T();
     const unsigned tb0 = lds0 + 2 * RC_BUF + (j & 1) * RC_BUF + q4 * RC_PL + (RC_GRD + wr * RC_CW + l15 - 1) * 16;
     const unsigned bias_a = lds0 + RC_BIAS + (2 * p + 1) * 128 + q4 * 16;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.x) + (size_t)at.b * a.x_bs, 0, a.T * 128, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)at.b * a.o_bs, 0, a.T * 128, 0x00020000);
+        const_cast<float*>(a.x) + (size_t)at.b() * a.x_bs, 0, Tu * 128, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)at.b() * a.o_bs, 0, Tu * 128, 0x00020000);
     if constexpr (p == 0) {
       // x_0 at this wave's columns (fp32, zero outside the utterance): the residual operand of pair 0
 #pragma unroll
       for (int g = 0; g < RC_G; ++g) {
         const int t = at.tb + wr * RC_CW + 16 * g + l15;
-        const int off = (t >= 0 && t < a.T) ? (t * 32 + 4 * q4) * 4 : G16_OOR;
+        const int off = (t >= 0 && t < Tu) ? (t * 32 + 4 * q4) * 4 : G16_OOR;
         xr[g][0] = g16_as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
         xr[g][1] = g16_as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(rx, off, 64, 0));
       }
@@ -263,7 +305,7 @@ __global__ void __launch_bounds__(512) g16_rc(ClChainArgs a, int total_tiles) {
     [[maybe_unused]] auto fetch_prv = [&](auto GG) {
       constexpr int g = decltype(GG)::value, sl = g & 1;
       const int col = wr * RC_CW + 16 * g + l15, t = at.tb + col;
-      const int off = (col >= H && col < H + R && t < a.T) ? (t * 32 + 4 * q4) * 4 : G16_OOR;
+      const int off = (col >= H && col < H + R && t < Tu) ? (t * 32 + 4 * q4) * 4 : G16_OOR;
       prv[sl][0] = __builtin_amdgcn_raw_buffer_load_b128(ro, off, 0, 0);
       prv[sl][1] = __builtin_amdgcn_raw_buffer_load_b128(ro, off, 64, 0);
     };
@@ -283,9 +325,9 @@ __global__ void __launch_bounds__(512) g16_rc(ClChainArgs a, int total_tiles) {
       v1 += xr[g][1];
       if constexpr (p + 1 < RC_NP) {
         xr[g][0] = v0; xr[g][1] = v1;                           // x_{p+1}
-        write_image(MASK, xw, col, q4, t, v0, v1);    // ... and the next pass's input image
+        write_image(MASK, xw, col, q4, t, Tu, v0, v1);    // ... and the next pass's input image
       } else {
-        const int off = (col >= H && col < H + R && t < a.T) ? (t * 32 + 4 * q4) * 4 : G16_OOR;
+        const int off = (col >= H && col < H + R && t < Tu) ? (t * 32 + 4 * q4) * 4 : G16_OOR;
         if constexpr (ACC) { v0 += g16_as_f32x4(prv[g & 1][0]); v1 += g16_as_f32x4(prv[g & 1][1]); }
         g16_div(v0, a.div); g16_div(v1, a.div);
         __builtin_amdgcn_raw_buffer_store_b128(g16_as_u32x4(v0), ro, off, 0, 0);
@@ -297,17 +339,14 @@ __global__ void __launch_bounds__(512) g16_rc(ClChainArgs a, int total_tiles) {
   // tiles that lie inside their utterance (all but the first and the last of an utterance) skip the zero masks of the
   // image writes: a UNIFORM branch between two instantiations of an item (a run-time flag inside one instantiation cost
   // four spilled registers and 17 %)
-  auto tile_inside = [&](int m) {
-    const TileAt at = tile_at(m);
-    return at.tb >= 0 && at.tb + RC_BT <= a.T;
+  auto tile_inside = [&](TileAt at) { return at.tb >= 0 && at.tb + RC_BT <= at.T(); };
+  auto conv1_item = [&](auto P, TileAt at, int m, int j, int ln) {
+    if (tile_inside(at)) conv1_item_m(P, std::false_type{}, at, m, j, ln);
+    else conv1_item_m(P, std::true_type{}, at, m, j, ln);
   };
-  auto conv1_item = [&](auto P, int m, int j, int ln) {
-    if (tile_inside(m)) conv1_item_m(P, std::false_type{}, m, j, ln);
-    else conv1_item_m(P, std::true_type{}, m, j, ln);
-  };
-  auto conv2_item = [&](auto P, int m, int j, int ln, f32x4 (&xr)[RC_G][2]) {
-    if (tile_inside(m)) conv2_item_m(P, std::false_type{}, m, j, ln, xr);
-    else conv2_item_m(P, std::true_type{}, m, j, ln, xr);
+  auto conv2_item = [&](auto P, TileAt at, int m, int j, int ln, f32x4 (&xr)[RC_G][2]) {
+    if (tile_inside(at)) conv2_item_m(P, std::false_type{}, at, m, j, ln, xr);
+    else conv2_item_m(P, std::true_type{}, at, m, j, ln, xr);
   };
 
   // ================= the pipeline: body m = iterations 3m, 3m + 1, 3m + 2 =================
@@ -322,33 +361,37 @@ __global__ void __launch_bounds__(512) g16_rc(ClChainArgs a, int total_tiles) {
     int ln = lane;
     asm volatile("" : "+v"(ln));                               // (per-lane addresses re-derived per body: registers)
     // ---- iteration 3m
-    if (is1) { if (m < n) conv1_item(P0{}, m, 3 * m, ln); }
-    else { if (m >= 1) conv2_item(P1{}, m - 1, 3 * m - 1, ln, xb); }
+    if (is1) { if (m < n) conv1_item(P0{}, tc, m, 3 * m, ln); }
+    else { if (m >= 1) conv2_item(P1{}, tq, m - 1, 3 * m - 1, ln, xb); }
     G16_BARRIER();
     // ---- iteration 3m + 1
-    if (is1) { if (m >= 1) conv1_item(P2{}, m - 1, 3 * m + 1, ln); }
-    else { if (m < n) conv2_item(P0{}, m, 3 * m, ln, xa); }
+    if (is1) { if (m >= 1) conv1_item(P2{}, tq, m - 1, 3 * m + 1, ln); }
+    else { if (m < n) conv2_item(P0{}, tc, m, 3 * m, ln, xa); }
     G16_BARRIER();
     // ---- iteration 3m + 2
     const bool stage = m + 1 < n;
     if (is1) {
-      if (m < n) conv1_item(P1{}, m, 3 * m + 2, ln);
+      if (m < n) conv1_item(P1{}, tc, m, 3 * m + 2, ln);
       if (stage) {
         g16_vmcnt<0>();                                        // (the pieces are this wave's only vector-memory traffic)
-        split_window(tile_at(m + 1), (m + 1) & 1, ln);
-        if (m + 2 < n) dma_window(tile_at(m + 2), ln);
+        const TileAt tn = tile_step(tc);
+        split_window(tn, (m + 1) & 1, ln);
+        if (m + 2 < n) dma_window(tile_step(tn), ln);
       }
     } else {
       if (stage) {
         // this wave's pieces went out three iterations ago, ahead of that body's loads and stores: everything older than
         // the final pass's operands below has to have landed anyway
         g16_vmcnt<0>();
-        split_window(tile_at(m + 1), (m + 1) & 1, ln);
-        if (m + 2 < n) dma_window(tile_at(m + 2), ln);
+        const TileAt tn = tile_step(tc);
+        split_window(tn, (m + 1) & 1, ln);
+        if (m + 2 < n) dma_window(tile_step(tn), ln);
       }
-      if (m >= 1) conv2_item(P2{}, m - 1, 3 * m + 1, ln, xb);
+      if (m >= 1) conv2_item(P2{}, tq, m - 1, 3 * m + 1, ln, xb);
     }
     G16_BARRIER();
+    tq = tc;
+    tc = tile_step(tc);
     // the tile of passes 0 / 1 becomes the "previous" tile
 #pragma unroll
     for (int g = 0; g < RC_G; ++g) { xb[g][0] = xa[g][0]; xb[g][1] = xa[g][1]; }
@@ -375,7 +418,17 @@ hipError_t launch_g16_rc(const ClChainArgs& a0, int B, hipStream_t s) {
   const int R = RC_BT - 2 * a.halo;
   if (R < 32) return hipErrorInvalidValue;
   a.tiles = (a.T + R - 1) / R;
-  const long total = (long)a.tiles * B;
+  if (B > 256) {                                  // (a tile cursor keeps the utterance in 8 bits: 256 utterances per launch)
+    for (int b0 = 0; b0 < B; b0 += 256) {
+      ClChainArgs c = a0;
+      c.x = a0.x + (size_t)b0 * a0.x_bs; c.out = a0.out + (size_t)b0 * a0.o_bs;
+      if (a0.glen) c.glen = a0.glen + b0;
+      if (hipError_t e2 = launch_g16_rc(c, B - b0 < 256 ? B - b0 : 256, s); e2 != hipSuccess) return e2;
+    }
+    return hipSuccess;
+  }
+  a.B = B;
+  const long total = (long)a.tiles * B;          // (ragged batch: the upper bound; the blocks count the real tiles themselves)
   if (total <= 0 || total > 0x7fffffffL) return hipErrorInvalidValue;
   int dev = 0, cus = 0;
   hipError_t e = hipGetDevice(&dev);

@@ -77,10 +77,19 @@ __global__ void __launch_bounds__(512) g16_rw(ClPairArgs a, int total_tiles) {
   const bool is1 = wave < 4;               // conv1 waves 0-3, conv2 waves 4-7 (w and w + 4 share a SIMD)
   const int wr = wave & 3;
 
-  // this block's run of tiles in the (utterance, tile) sequence
+  // this block's run of tiles in the (utterance, tile) sequence; ragged batch (ClPairArgs::glen): utterance b has
+  // ceil(glen[b] * grate / R2) tiles instead of a.tiles
   const int nb = gridDim.x, bid = blockIdx.x;
-  const int per = total_tiles / nb, extra = total_tiles - per * nb;
-  const int lo = bid * per + (bid < extra ? bid : extra), n = per + (bid < extra ? 1 : 0);
+  int lo_b, lo_tile, n;
+  if (a.glen) {
+    g16_ragged_run(a.glen, a.B, a.grate, R2, nb, bid, lo_b, lo_tile, n);
+  } else {
+    const int per = total_tiles / nb, extra = total_tiles - per * nb;
+    const int lo = bid * per + (bid < extra ? bid : extra);
+    n = per + (bid < extra ? 1 : 0);
+    lo_b = lo / a.tiles;
+    lo_tile = lo - lo_b * a.tiles;
+  }
   const int p1 = a.dil * p2;
   const int xrows = RW_BT + (K - 1) * a.dil;
 
@@ -209,21 +218,43 @@ __global__ void __launch_bounds__(512) g16_rw(ClPairArgs a, int total_tiles) {
   // (b, t0) of a tile: one integer division per BLOCK -- the loop carries the coordinates of tiles i - 1 .. i + 2 and
   // steps them with scalar compares (a per-iteration id / tiles costs ~20 vector instructions a call, and vector issue slots
   // are what this kernel is short of)
-  struct TileAt { int b, t0; };
+  // a tile: first output column, and utterance | extent << 8 in ONE scalar (B <= 256 per launch, T < 2^24): a cursor is two
+  // scalar registers, as it was before the extent became per-utterance
+  struct TileAt {
+    int t0; unsigned bT;
+    __device__ int b() const { return (int)(bT & 255u); }
+    __device__ int T() const { return (int)(bT >> 8); }
+  };
+  // (the ragged-batch parameters are re-read from the kernel-argument segment in the rare branch that needs them: kept
+  // in scalar registers across the persistent loop they push other scalars into vector lanes -- the trick of g16_convp)
+  auto T_of = [&](int b) -> int {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) ClPairArgs* KArgs;
+    KArgs ea = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ea));                             // (opaque: not hoisted out of the branch, not kept live)
+    const int* gl = ea->glen;
+    if (!gl) return ea->T;
+    const int nB = ea->B;
+    return __builtin_amdgcn_readfirstlane(gl[b < nB ? b : nB - 1]) * ea->grate;   // (a cursor may step past the last utterance: never used then)
+#else
+    return 0;
+#endif
+  };
   auto tile_step = [&](TileAt t) -> TileAt {
     t.t0 += R2;
-    if (t.t0 >= a.tiles * R2) { t.t0 = 0; ++t.b; }
+    if (t.t0 >= t.T()) { t.t0 = 0; const int nb_ = t.b() + 1; t.bT = (unsigned)(nb_ & 255) | ((unsigned)T_of(nb_) << 8); }
     return t;
   };
   auto dma_window = [&](TileAt at, int lane) {
-    const char* xb = reinterpret_cast<const char*>(a.x + (size_t)at.b * a.x_bs);
+    const char* xb = reinterpret_cast<const char*>(a.x + (size_t)at.b() * a.x_bs);
     const int tb = at.t0 - p2 - p1;
+    const int Tu = at.T();
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int p = wave + 8 * u;
       if (8 * p < xrows) {
         int t = tb + 8 * p + (lane >> 3);
-        t = t < 0 ? 0 : (t >= a.T ? a.T - 1 : t);
+        t = t < 0 ? 0 : (t >= Tu ? Tu - 1 : t);
         const char* gp = xb + ((unsigned)t * 128u + (unsigned)(lane & 7) * 16u);   // (uniform base + 32-bit lane offset)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
                                          (__attribute__((address_space(3))) void*)(STG + p * 1024), 16, 0, 0);
@@ -247,11 +278,12 @@ __global__ void __launch_bounds__(512) g16_rw(ClPairArgs a, int total_tiles) {
       v[q][1] = *reinterpret_cast<const f32x4*>(sp + 16);
     }
     RW_STAMP(13);
-    if (tb < 0 || tb + RW_WRX > a.T) {                       // (uniform: a window that leaves the utterance)
+    const int Tu = at.T();
+    if (tb < 0 || tb + RW_WRX > Tu) {                        // (uniform: a window that leaves the utterance)
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int t = tb + r[q];
-        if (t < 0 || t >= a.T) { v[q][0] = f32x4{0.f, 0.f, 0.f, 0.f}; v[q][1] = v[q][0]; }
+        if (t < 0 || t >= Tu) { v[q][0] = f32x4{0.f, 0.f, 0.f, 0.f}; v[q][1] = v[q][0]; }
       }
     }
 #pragma unroll
@@ -268,8 +300,8 @@ __global__ void __launch_bounds__(512) g16_rw(ClPairArgs a, int total_tiles) {
 
   // ================= prologue: the first tile's window split, the second one's requested =================
   TileAt tc, tn, tn2, tp;                                    // tiles i, i + 1, i + 2, i - 1
-  tc.b = lo / a.tiles;
-  tc.t0 = (lo - tc.b * a.tiles) * R2;
+  tc.t0 = lo_tile * R2;
+  tc.bT = (unsigned)(lo_b & 255) | ((unsigned)T_of(lo_b) << 8);
   tn = tile_step(tc);
   tn2 = tile_step(tn);
   tp = tc;
@@ -309,9 +341,11 @@ __global__ void __launch_bounds__(512) g16_rw(ClPairArgs a, int total_tiles) {
       if (i < n) { prime_hi(xb0); nBl = g16_lds_read<RW_XIMG>(xb0); }
       RW_STAMP(2);
       if (i < n) {
-        const int t0 = tc.t0;
+        TileAt at = tc;
+        asm volatile("" : "+s"(at.t0), "+s"(at.bT));      // (fresh values inside the role's branch: gen16_rc.hip)
+        const int t0 = at.t0, Tc = at.T();
         char* const ti = TI + (i & 1) * RW_TBUF;
-        const bool inside = t0 - p2 >= 0 && t0 - p2 + RW_BT <= a.T;   // (uniform: every conv1 column of the tile is in the utterance)
+        const bool inside = t0 - p2 >= 0 && t0 - p2 + RW_BT <= Tc;    // (uniform: every conv1 column of the tile is in the utterance)
         g16_for<RW_G>([&](auto GG) {
           constexpr int g = decltype(GG)::value;
           f32x4 hh0, hh1, cr0, cr1;
@@ -323,7 +357,7 @@ __global__ void __launch_bounds__(512) g16_rw(ClPairArgs a, int total_tiles) {
           const int col = wr * RW_CW + 16 * g + l15;
           const int tt = t0 - p2 + col;
           f32x4 t0v = hh0 + cr0 * (1.f / 2048.f), t1v = hh1 + cr1 * (1.f / 2048.f);
-          if (!inside && !(tt >= 0 && tt < a.T)) { t0v = f32x4{0.f, 0.f, 0.f, 0.f}; t1v = t0v; }
+          if (!inside && !(tt >= 0 && tt < Tc)) { t0v = f32x4{0.f, 0.f, 0.f, 0.f}; t1v = t0v; }
           if (!(diag & 8)) {
             f16x4 eh, el;
             char* dst = ti + (q4 >> 1) * RW_PLT + col * 16 + 8 * (q4 & 1);
@@ -355,13 +389,15 @@ __global__ void __launch_bounds__(512) g16_rw(ClPairArgs a, int total_tiles) {
       if (i >= 1) { prime_hi(tb0); nBl = g16_lds_read<RW_TIMG>(tb0); }
       RW_STAMP(2);
       if (i >= 1) {
-        const int b = tp.b, t0 = tp.t0;
+        TileAt at = tp;
+        asm volatile("" : "+s"(at.t0), "+s"(at.bT));
+        const int b = at.b(), t0 = at.t0, Tp = at.T();
         const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(a.x) + (size_t)b * a.x_bs, 0, a.T * 128, 0x00020000);
-        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)b * a.o_bs, 0, a.T * 128, 0x00020000);
+            const_cast<float*>(a.x) + (size_t)b * a.x_bs, 0, Tp * 128, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)b * a.o_bs, 0, Tp * 128, 0x00020000);
         auto off_of = [&](int g) -> int {
           const int r = wr * RW_CW + 16 * g + l15;
-          return (r < R2 && t0 + r < a.T) ? ((t0 + r) * 32 + 4 * q4) * 4 : G16_OOR;
+          return (r < R2 && t0 + r < Tp) ? ((t0 + r) * 32 + 4 * q4) * 4 : G16_OOR;
         };
         // residual (and previous ResBlock sum) operands: one group ahead where the registers allow (K = 7), with the
         // group otherwise
@@ -418,7 +454,17 @@ static hipError_t launch_g16_rw_k(ClPairArgs a, int B, hipStream_t s) {
   if (e != hipSuccess) return e;
   constexpr int R2 = RW_BT - (K - 1);
   a.tiles = (a.T + R2 - 1) / R2;
-  const long total = (long)a.tiles * B;
+  if (B > 256) {                                // (a tile cursor keeps the utterance in 8 bits: 256 utterances per launch)
+    for (int b0 = 0; b0 < B; b0 += 256) {
+      ClPairArgs c = a;
+      c.x = a.x + (size_t)b0 * a.x_bs; c.out = a.out + (size_t)b0 * a.o_bs;
+      if (a.glen) c.glen = a.glen + b0;
+      if (hipError_t e2 = launch_g16_rw_k<K, ACC>(c, B - b0 < 256 ? B - b0 : 256, s); e2 != hipSuccess) return e2;
+    }
+    return hipSuccess;
+  }
+  a.B = B;
+  const long total = (long)a.tiles * B;        // (ragged batch: the upper bound; the blocks count the real tiles themselves)
   if (total <= 0 || total > 0x7fffffffL) return hipErrorInvalidValue;
   int dev = 0, cus = 0;
   e = hipGetDevice(&dev);
@@ -432,7 +478,12 @@ static hipError_t launch_g16_rw_k(ClPairArgs a, int B, hipStream_t s) {
 
 hipError_t launch_g16_rw(const ClPairArgs& a0, int B, hipStream_t s) {
   ClPairArgs a = a0;
+  // (timing-only ablations, results WRONG by construction: experiment builds only -- the product build keeps terms == 3)
+#ifdef VSP_EXPERIMENTS
   static const int diag = []() { const char* e = getenv("VSP_RW_DIAG"); return e ? atoi(e) : 0; }();
+#else
+  constexpr int diag = 0;
+#endif
   a.terms = 3 | (diag << 8);
   if (!g16_rw_supported(a0.C, a0.K, a0.dil, a0.terms) || a.T <= 0 || B <= 0 || (a.x_bs & 3) || (a.o_bs & 3) ||
       (reinterpret_cast<uintptr_t>(a.x) & 15) || (reinterpret_cast<uintptr_t>(a.out) & 15) || a.x == a.out ||

@@ -88,12 +88,18 @@ struct ClConvArgs {
   const uint16_t* x_img; long xi_bs; int xi_tpad;   // batch stride in halfs, padded rows per plane
   uint16_t* o_img; long oi_bs; int oi_tpad; float oi_slope;
   int pt_gx, pt_gy, pt_total;               // set by the persistent launcher: time tiles, row groups, tiles in all
+  // Ragged batch (round 5, "trimmed tails"): glen[b] (device, int32) = frames of utterance b this launch computes; its
+  // extents are then T_in = glen[b] * g_in, Nq = T_in + (Nq - T_in of the launch), T_store = glen[b] * g_store instead of
+  // the launch-wide values above (which stay the MAXIMUM: grid size, strides, image padding).  Rows at and beyond an
+  // utterance's own extent read as zero and are never stored: the tensor ENDS there for that utterance.  NULL = uniform.
+  const int* glen; int g_in, g_store;
 };
 constexpr int CL_IMG_PADF = 64, CL_IMG_PADB = 320;
 inline int cl_img_tpad(int T) { return T + CL_IMG_PADF + CL_IMG_PADB; }
 inline size_t cl_img_halfs(int C, int T) { return (size_t)C * 2 * cl_img_tpad(T); }   // per utterance
-// zero the pad rows of B utterances' images (the data rows are the producer's)
-hipError_t launch_cl_img_zero_pads(uint16_t* img, int B, int C, int T, hipStream_t s);
+// zero the pad rows of B utterances' images (the data rows are the producer's); glen != NULL: utterance b's data rows end
+// at glen[b] * grate (<= T), the CL_IMG_PADB zero rows follow there
+hipError_t launch_cl_img_zero_pads(uint16_t* img, int B, int C, int T, hipStream_t s, const int* glen = nullptr, int grate = 0);
 
 // Fused ResBlock1 conv pair on channels-last activations (gen16.hip):
 //   out = x + conv2(lrelu(conv1(lrelu(x), dil) + b1), 1) + b2  [+ out] [/ div];  x != out.
@@ -109,6 +115,8 @@ struct ClPairArgs {
   int ring;                                 // 1: the LDS-ring pair kernel (g16_pair) even where the register-weights one exists
   int tiles;                                // set by the launcher: tiles per utterance
   int xrows;                                // set by the launcher: staged window rows
+  const int* glen; int grate;               // ragged batch (see ClConvArgs): utterance b's T = glen[b] * grate; NULL = uniform
+  int B;                                    // set by the launcher (persistent kernels walk the utterances themselves)
 };
 // Fused ResBlock1 CHAIN on channels-last activations (gen16.hip): np conv pairs back to back in one launch,
 //   x_{p+1} = x_p + conv2_p(lrelu(conv1_p(lrelu(x_p), dil_p) + b1_p), 1) + b2_p,   out = x_np [+ out] [/ div];  x != out.
@@ -124,6 +132,8 @@ struct ClChainArgs {
   int terms;
   int ring;                                 // 1: the LDS-ring chain kernel (g16_chain) even where the register-weights one exists
   int tiles, halo;                          // set by the launcher: tiles per utterance, columns recomputed per side
+  const int* glen; int grate;               // ragged batch (see ClConvArgs): utterance b's T = glen[b] * grate; NULL = uniform
+  int B;                                    // set by the launcher
 };
 // the kernel-3 ResBlock of the 32-channel stage as a role pipeline with the weights in registers (gen16_rc.hip);
 // launch_g16_chain routes there unless ClChainArgs::ring (VSP_CHAIN_RING=1) asks for the LDS-ring chain (bit-identical)
@@ -153,7 +163,16 @@ hipError_t launch_spec_to_mel(const float* spec, const float* basis, const int* 
 hipError_t launch_transpose_ct(const float* x, long x_bs, long x_cs, float* y, long y_bs, int y_ts, int B, int C,
                                int T, hipStream_t s);
 hipError_t launch_conv_post_cl(const float* x, long x_bs, int x_ts, const float* w, int C, int K, float slope,
-                               float* o, long o_bs, int B, int T, hipStream_t s);
+                               float* o, long o_bs, int B, int T, hipStream_t s, const int* glen = nullptr, int grate = 0);
+// Trimmed tails (round 5).  The generator's input behind an utterance's last frame is exactly zero (reference
+// models.py:720: z * x_mask), so its output there is a bias-driven signal that depends on the distance to the utterance's
+// end and to the tensor's end only: periodic in one frame once `halo` frames (the receptive field) away from both.
+//   gen_plan:  glen[b] = len[b] + 2 halo + 1 where that is < T (else T): the frames the generator computes for b;
+//   gen_tail_fill:  frames [len + halo + 1, T - halo) of o[b] = frame len + halo (the steady state), frames
+//                   [T - halo, T) = frames [len + halo + 1, len + 2 halo + 1) (the computed tensor end); up = samples per frame.
+hipError_t launch_gen_plan(const int64_t* lengths, int B, int T, int halo, int* glen, hipStream_t s);
+hipError_t launch_gen_tail_fill(float* o, long o_bs, const int64_t* lengths, const int* glen, int B, int T, int halo, int up,
+                                hipStream_t s);
 
 // ------------------------------------------------------------------------------------------
 // attention with windowed relative position (reference attentions.py:148-179), f32 MFMA.

@@ -117,6 +117,8 @@ struct vsp_ctx {
   bool pp_pairs = true;           // k3 / k7 conv pairs of the 128-channel stage as one launch (g16_pp; VSP_PP=0: two launches)
   bool pair_ring = false;         // VSP_PAIR=ring: the LDS-ring pair kernel on the 32-channel stage instead of g16_rw
   bool chain_ring = false;        // VSP_CHAIN_RING=1: the LDS-ring chain kernel (g16_chain) instead of g16_rc
+  bool trim_tails = true;         // ragged batches: the generator runs each utterance to length + 2 halo + 1 frames and fills the
+                                  // padded tail from the steady state (VSP_TRIM_TAILS=0: to the padded length; bit-identical)
   int64_t noise_first = 0;        // stream index of element 0 of a library-drawn noise tensor (vsp_set_noise_offset)
   bool adopted_pending = false;   // an adopted arena whose header has not been checked yet (vsp_commit_adopted_weights)
   int gen_mode = 1;  // 0: f32 MFMA channel-major generator, 1: split-f16 (fp32-accurate) channels-last generator,
@@ -133,6 +135,8 @@ struct vsp_ctx {
   bool prof_on = false;
   std::vector<hipEvent_t> ev_pool;
   std::vector<int> ev_cls;           // class of event pair i (events 2i, 2i+1)
+  std::vector<int> ev_fam;           // kernel family of event pair i (VSP_FAM_* in vispeech_hip.h)
+  std::vector<double> ev_flops, ev_bytes;   // algorithmic work of the launch of event pair i
   size_t ev_used = 0;
   int64_t prof_launches[VSP_PROF_CLASSES] = {};
   double prof_flops[VSP_PROF_CLASSES] = {};

@@ -485,6 +485,21 @@ class Engine:
         return int(n.value), float(ms.value), float(fl.value), float(by.value), float(bx.value)
 
 
+    _FAMILY_KINDS = {0: "other", 1: "conv", 2: "ups", 3: "pair", 4: "chain", 5: "pre"}
+
+    def profile_read_families(self, cls: int = _lib.PROF_GENERATOR, max_families: int = 64):
+        """Per kernel family of one class since the last reset (call BEFORE profile_read(reset=True)):
+        [{kind, channels, launches, ms, flops, bytes}], largest total time first."""
+        m = int(max_families)
+        fam, n = (C.c_int * m)(), (C.c_int64 * m)()
+        ms, fl, by = (C.c_double * m)(), (C.c_double * m)(), (C.c_double * m)()
+        k = self.lib.vsp_profile_read_families(self.ctx, int(cls), m, fam, n, ms, fl, by)
+        _lib.check(min(k, 0), self.ctx, "vsp_profile_read_families")
+        out = [dict(kind=self._FAMILY_KINDS.get(fam[i] & 7, "other"), channels=32 << (fam[i] >> 3), launches=int(n[i]),
+                    ms=float(ms[i]), flops=float(fl[i]), bytes=float(by[i])) for i in range(k)]
+        return sorted(out, key=lambda d: -d["ms"])
+
+
 def rq_spline(x, uw, uh, ud, inverse: bool = False, tail_bound: float = 5.0):
     """piecewise_rational_quadratic_transform(..., tails='linear') on the GPU (reference
     transforms.py:12-193).  x [...]; uw, uh [..., nb]; ud [..., nb-1]."""

@@ -3,7 +3,12 @@ names and argument order, tensors in, CUDA tensors out.  The DFT matrix of the s
 arena, so the engine (``net._engine`` of a ``vispeech_amd.models.SynthesizerTrn``) is passed as a keyword; ``n_fft``
 and ``win_size`` must be that model's ``filter_length`` (the reference always calls these with
 ``hps.data.filter_length`` / ``win_length`` of equal value, data_utils.py:60-64).  ``center`` must be False, as in
-every call of the reference."""
+every call of the reference.
+
+Parity status: the linear spectrogram is pinned to ``torch.stft`` (tests/test_mel.py); the MEL BASIS is **parity
+unpinned** -- librosa (the reference's source of it, mel_processing.py:14, 78, 96) and torchaudio are absent from the
+build image, so ``vsp_mel_filterbank`` is a restatement of librosa's published Slaney algorithm checked only against
+the oracle's independent restatement and one documented known answer."""
 from typing import Optional
 
 import torch
