@@ -226,7 +226,8 @@ def test_oracle_parity_medium_batch(net, oracle):
 
 def test_sharded_batch_equals_unsharded(net):
     """SURVEY gotcha G6: with every shard padded to the global T_f, per-utterance results do not
-    depend on which shard they ran in (bit-exact: same kernels, same tiles per utterance)."""
+    depend on which shard they ran in -- bit-exact HERE, where both sides are small enough to select the same kernels
+    (same tiles per utterance); at other shard sizes within the parity tolerance: the test below."""
     from vispeech_amd.synth import synth_batch
     batch = synth_batch(4, seed=33, mean_phonemes=16, std_phonemes=4, min_phonemes=8, max_phonemes=24,
                         mean_frames=70, jitter_frames=20)
@@ -242,6 +243,36 @@ def test_sharded_batch_equals_unsharded(net):
     a, b = run(slice(0, 2)), run(slice(2, 4))
     np.testing.assert_array_equal(to_np(full[0]), np.concatenate([to_np(a[0]), to_np(b[0])], axis=0))
     np.testing.assert_array_equal(to_np(full[2][0]), np.concatenate([to_np(a[2][0]), to_np(b[2][0])], axis=0))
+
+
+def test_c3_rank_slice_matches_the_unsharded_run(net):
+    """Shard-size independence, stated truthfully: utterances [24, 32) of the C3 batch run as the
+    rank-3-of-8 slice (global frame padding, its own rows of the noise) against the same rows of the N = 1 run.  The
+    frame-rate convolutions pick their kernel from the size of the LAUNCH (conv_mfma.hip launch_conv: the channel-split
+    and latency forms on grids that do not fill the chip), and a split-k sum adds in another order -- so a shard is NOT
+    bit-equal to the unsharded run in general (it is when both sides select the same kernels: the 4 -> 2 + 2 test
+    above).  What holds at every shard size is the parity tolerance itself, with a wide margin: 1e-5 on the latent,
+    1e-5 of the peak on the waveform (measured 2e-7 / 1e-6)."""
+    from vispeech_amd.sharding import shard_range
+    from vispeech_amd.synth import workload
+    b = workload("C3")
+    dev = net.device
+    t = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
+    tf = int(b["frame_lengths"].max())
+
+    def run(sl):
+        o, _, (z, *_), *_ = net.infer(t(b["phonemes"][sl]), t(b["lengths"][sl]), sid=t(b["sid"][sl]), noise_scale=0.667,
+                                      duration_control=t(b["duration"][sl]), pitch_control=t(b["f0"][sl]),
+                                      energy_control=t(b["energy"][sl]), noise=t(b["noise"][sl]), t_f=tf)
+        return to_np(o), to_np(z)
+    lo, hi = shard_range(64, 3, 8)
+    assert (lo, hi) == (24, 32)
+    o_all, z_all = run(slice(0, 64))
+    o_sh, z_sh = run(slice(lo, hi))
+    assert o_sh.shape == o_all[lo:hi].shape
+    ez, eo = rel_err(z_sh, z_all[lo:hi]), rel_err(o_sh, o_all[lo:hi])
+    print(f"rank 3 of 8 vs unsharded: z {ez:.2e}  o {eo:.2e}  bit-equal: {np.array_equal(o_sh, o_all[lo:hi])}")
+    assert ez <= STAGE_TOL and eo <= 1e-5
 
 
 def test_valid_region_properties(net):

@@ -1,6 +1,6 @@
 """Trimmed tails (round 5): behind an utterance's last frame the generator's input is exactly zero (reference
 models.py:720: `z * x_mask`; `dec` itself applies no mask, models.py:271-290), so the library computes every utterance
-only to `length + 2 halo + 1` frames and fills the rest of the padded waveform -- which the reference still returns --
+only to `length + 13 + 1 + 13` frames (output frame F depends on input frames F - 13 .. F + 13, sample-exact) and fills the rest of the padded waveform -- which the reference still returns --
 from the steady state and the computed tensor end (vispeech_amd/csrc/kernels.h, launch_gen_tail_fill).  The FULL padded
 output must equal the to-the-padded-length run (VSP_TRIM_TAILS=0, second implementation) bit for bit, whichever kernels
 the other switches select, and the oracle within the usual tolerance.  Needs an MI355X: `pytest -m gpu`."""
@@ -85,9 +85,10 @@ def run(net, b, sl=slice(None), t_f=None, **kw):
                      noise=t(b["noise"][sl]), t_f=t_f, **kw)
 
 
-# padded length 150: untrimmed (150), barely untrimmed (T - L = 28 and 29: length + 29 >= T), the shortest trimmed tail
-# (T - L = 30: ONE steady-state frame to fill), ordinary, short, and tiny utterances
-FRAMES = [150, 122, 121, 120, 119, 96, 60, 31, 7, 1]
+# padded length 150; an utterance is computed to length + 13 + 1 + 13 frames where that is shorter: untrimmed (150, 124,
+# 123: length + 27 >= T), the shortest trimmed tails (122: the steady-state frame is the LAST one before the tensor end's
+# 13 frames, nothing to fill between; 121: one frame to fill), ordinary, short, and tiny utterances
+FRAMES = [150, 124, 123, 122, 121, 120, 96, 60, 31, 7, 1]
 
 
 def test_halo_constant(net):

@@ -14,6 +14,8 @@ using namespace vsp;
 
 namespace {
 
+void generator_frame_dependence(const vsp_config& c, int pre_k, int post_k, int& back, int& fwd);   // (defined below)
+
 struct T3 {
   float* p = nullptr;
   long bs = 0, cs = 0;
@@ -477,13 +479,16 @@ void run_generator_cl(Run& r, int B, int T, T3 z, const int64_t* in_lengths, con
   // Trimmed tails (round 5; VSP_TRIM_TAILS=0: off, second implementation, bit-identical).  Behind an utterance's last frame
   // the input is exactly zero (z * x_mask, reference models.py:720), so the output there depends on the distance to the
   // utterance's end and to the tensor's end only: every kernel below treats utterance b's tensor as ENDING after
-  // len_b + 2 halo + 1 frames (kernels.h, ClConvArgs::glen) -- frames [0, len + halo) come out as in the padded run, frame
-  // len + halo is the steady state (periodic in one frame), the last halo frames are the tensor end's -- and
+  // len_b + back + 1 + fwd frames (kernels.h, ClConvArgs::glen) -- frames [0, len + back) come out as in the padded run,
+  // frame len + back is the steady state (periodic in one frame), the last fwd frames are the tensor end's -- and
   // gen_tail_fill writes the rest of the padded tensor from those.  The reference's full padded output, bit for bit.
-  const int halo = vsp_generator_halo_frames(r.ctx);
+  // (back / fwd: output frame F depends on input frames [F - back, F + fwd], sample-exact: 13 / 13 for configs/config.json.
+  // A tensor that ends after E frames is exact up to frame E - 1 - fwd; frame len + back is the first steady one.)
+  int back = 0, fwd = 0;
+  generator_frame_dependence(c, m.g_pre.K, m.post_k, back, fwd);
   int* glen_all = r.ctx->trim_tails ? reinterpret_cast<int*>(r.ws.bytes((size_t)B * sizeof(int))) : nullptr;
-  const bool trim = glen_all && in_lengths && T > 2 * halo + 1;
-  if (trim && !r.dry() && r.ok()) r.chk(launch_gen_plan(in_lengths, B, T, halo, glen_all, r.s), "gen_plan");
+  const bool trim = glen_all && in_lengths && T > back + fwd + 1;
+  if (trim && !r.dry() && r.ok()) r.chk(launch_gen_plan(in_lengths, B, T, back, fwd, glen_all, r.s), "gen_plan");
   // the channels-last kernels address one utterance's tensor with 32-bit byte offsets (buffer descriptors)
   // (the operand images -- C * 4 * (T + 384) bytes per utterance -- are addressed the same way)
   if (mx * sizeof(float) >= (size_t)1 << 31 || (timg && mx_img * sizeof(float) >= (size_t)1 << 31)) {
@@ -579,7 +584,7 @@ void run_generator_cl(Run& r, int B, int T, T3 z, const int64_t* in_lengths, con
   if (!r.dry() && r.ok()) {
     r.chk(launch_conv_post_cl(buf[cur], Tn * ch, ch, r.A(m.post_wt), m.post_c, m.post_k, 0.01f, o, Tn, B, (int)Tn, r.s,
                               trim ? glen_all : nullptr, (int)(Tn / T)), "conv_post_cl");
-    if (trim) r.chk(launch_gen_tail_fill(o, Tn, in_lengths, glen_all, B, T, halo, (int)(Tn / T), r.s), "gen_tail_fill");
+    if (trim) r.chk(launch_gen_tail_fill(o, Tn, in_lengths, glen_all, B, T, back, fwd, (int)(Tn / T), r.s), "gen_tail_fill");
   }
 }
 
@@ -592,6 +597,31 @@ int check_ready(vsp_ctx* ctx) {
   if (!ctx) return VSP_ERR_ARG;
   if (!ctx->ready) return ctx->fail(VSP_ERR_STATE, "weights not finalised");
   return VSP_OK;
+}
+
+// Exact dependence of the generator's output FRAMES on its input frames, from the configuration (sample-exact supports;
+// vsp_generator_halo_frames below is the coarser per-stage bound the streamed vocoder uses): output frame F depends on
+// input frames [F - back, F + fwd].  An impulse at input position 0 reaches output samples [lo, hi]: conv_pre widens the
+// support by its padding, a transposed convolution (k, s, p) maps [lo, hi] to [lo s - p, hi s - p + k - 1], a stage's
+// ResBlocks widen it by max_k sum_d ((k - 1) d / 2 + (k - 1) / 2), conv_post by its padding.
+void generator_frame_dependence(const vsp_config& c, int pre_k, int post_k, int& back, int& fwd) {
+  long lo = -(pre_k - 1) / 2, hi = (pre_k - 1) / 2, up = 1;
+  for (int i = 0; i < c.n_upsamples; ++i) {
+    const long s = c.upsample_rates[i], k = c.upsample_kernel_sizes[i], p = (k - s) / 2;
+    lo = lo * s - p; hi = hi * s - p + k - 1; up *= s;
+    long rb = 0;
+    for (int j = 0; j < c.n_resblock_kernels; ++j) {
+      long acc = 0;
+      const long kk = c.resblock_kernel_sizes[j];
+      for (int d = 0; d < c.n_resblock_dilations; ++d) acc += (kk - 1) * c.resblock_dilation_sizes[j][d] / 2 + (kk - 1) / 2;
+      rb = std::max(rb, acc);
+    }
+    lo -= rb; hi += rb;
+  }
+  lo -= (post_k - 1) / 2; hi += (post_k - 1) / 2;
+  // output frame F = samples [up F, up F + up - 1] depends on input frames f with up f + lo <= n <= up f + hi
+  back = (int)(hi / up);                     // F - floor(hi / up)
+  fwd = (int)((up - 1 - lo) / up);           // F + floor((up - 1 - lo) / up)
 }
 
 long total_upsample(const vsp_config& c) {

@@ -122,45 +122,45 @@ hipError_t launch_cl_img_zero_pads(uint16_t* img, int B, int C, int T, hipStream
 
 // ------------------------------------------------------------------------------------------------------------
 // Trimmed tails (kernels.h).  gen_plan: the frames the generator computes per utterance.
-__global__ void gen_plan_kernel(const int64_t* __restrict__ lengths, int B, int T, int halo, int* __restrict__ glen) {
+__global__ void gen_plan_kernel(const int64_t* __restrict__ lengths, int B, int T, int ext, int* __restrict__ glen) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   long len = lengths[b];
   len = len < 0 ? 0 : len;
-  const long e = len + 2 * halo + 1;
+  const long e = len + ext;
   glen[b] = e < T ? (int)e : T;
 }
-hipError_t launch_gen_plan(const int64_t* lengths, int B, int T, int halo, int* glen, hipStream_t s) {
-  if (!lengths || !glen || B <= 0 || T <= 0 || halo < 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(gen_plan_kernel, dim3((B + 63) / 64), dim3(64), 0, s, lengths, B, T, halo, glen);
+hipError_t launch_gen_plan(const int64_t* lengths, int B, int T, int back, int fwd, int* glen, hipStream_t s) {
+  if (!lengths || !glen || B <= 0 || T <= 0 || back < 0 || fwd < 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gen_plan_kernel, dim3((B + 63) / 64), dim3(64), 0, s, lengths, B, T, back + 1 + fwd, glen);
   return hipGetLastError();
 }
-// gen_tail_fill: one block per utterance.  The computed tensor end -- frames [len + halo + 1, len + 2 halo + 1) -- is read
-// into LDS first (the steady-state fill overwrites it), then frames [len + halo + 1, T - halo) get the steady-state frame
-// len + halo and frames [T - halo, T) the saved tensor end.  Utterances the plan did not trim (glen[b] == T) are skipped.
+// gen_tail_fill: one block per utterance.  The computed tensor end -- frames [len + back + 1, len + back + 1 + fwd) -- is
+// read into LDS first (the steady-state fill overwrites it), then frames [len + back + 1, T - fwd) get the steady-state
+// frame len + back and frames [T - fwd, T) the saved tensor end.  Utterances the plan did not trim (glen[b] == T) are skipped.
 __global__ void __launch_bounds__(1024) gen_tail_fill_kernel(float* __restrict__ o, long o_bs, const int64_t* __restrict__ lengths,
-                                                             const int* __restrict__ glen, int T, int halo, int up) {
-  extern __shared__ float tail[];                 // [halo * up]
+                                                             const int* __restrict__ glen, int T, int back, int fwd, int up) {
+  extern __shared__ float tail[];                 // [fwd * up]
   const int b = blockIdx.x;
   if (glen[b] >= T) return;
   long len = lengths[b];
   len = len < 0 ? 0 : len;
   float* ob = o + (size_t)b * o_bs;
-  const long s0 = (len + halo) * up;              // the steady-state frame
-  const long e0 = s0 + up;                        // the computed tensor end: halo frames from here
-  const int nt = halo * up;
+  const long s0 = (len + back) * up;              // the steady-state frame
+  const long e0 = s0 + up;                        // the computed tensor end: fwd frames from here
+  const int nt = fwd * up;
   for (int i = threadIdx.x; i < nt; i += blockDim.x) tail[i] = ob[e0 + i];
   __syncthreads();
-  const long fill_end = (long)(T - halo) * up;
+  const long fill_end = (long)(T - fwd) * up;
   for (long i = e0 + threadIdx.x; i < fill_end; i += blockDim.x) ob[i] = ob[s0 + (i - e0) % up];
   for (int i = threadIdx.x; i < nt; i += blockDim.x) ob[fill_end + i] = tail[i];
 }
-hipError_t launch_gen_tail_fill(float* o, long o_bs, const int64_t* lengths, const int* glen, int B, int T, int halo, int up,
-                                hipStream_t s) {
-  if (!o || !lengths || !glen || B <= 0 || T <= 0 || halo < 0 || up <= 0) return hipErrorInvalidValue;
-  const size_t lds = (size_t)halo * up * sizeof(float);
+hipError_t launch_gen_tail_fill(float* o, long o_bs, const int64_t* lengths, const int* glen, int B, int T, int back, int fwd,
+                                int up, hipStream_t s) {
+  if (!o || !lengths || !glen || B <= 0 || T <= 0 || back < 0 || fwd < 0 || up <= 0) return hipErrorInvalidValue;
+  const size_t lds = (size_t)fwd * up * sizeof(float);
   if (lds > 64 * 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(gen_tail_fill_kernel, dim3(B), dim3(1024), lds, s, o, o_bs, lengths, glen, T, halo, up);
+  hipLaunchKernelGGL(gen_tail_fill_kernel, dim3(B), dim3(1024), lds, s, o, o_bs, lengths, glen, T, back, fwd, up);
   return hipGetLastError();
 }
 

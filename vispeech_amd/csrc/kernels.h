@@ -166,13 +166,14 @@ hipError_t launch_conv_post_cl(const float* x, long x_bs, int x_ts, const float*
                                float* o, long o_bs, int B, int T, hipStream_t s, const int* glen = nullptr, int grate = 0);
 // Trimmed tails (round 5).  The generator's input behind an utterance's last frame is exactly zero (reference
 // models.py:720: z * x_mask), so its output there is a bias-driven signal that depends on the distance to the utterance's
-// end and to the tensor's end only: periodic in one frame once `halo` frames (the receptive field) away from both.
-//   gen_plan:  glen[b] = len[b] + 2 halo + 1 where that is < T (else T): the frames the generator computes for b;
-//   gen_tail_fill:  frames [len + halo + 1, T - halo) of o[b] = frame len + halo (the steady state), frames
-//                   [T - halo, T) = frames [len + halo + 1, len + 2 halo + 1) (the computed tensor end); up = samples per frame.
-hipError_t launch_gen_plan(const int64_t* lengths, int B, int T, int halo, int* glen, hipStream_t s);
-hipError_t launch_gen_tail_fill(float* o, long o_bs, const int64_t* lengths, const int* glen, int B, int T, int halo, int up,
-                                hipStream_t s);
+// end and to the tensor's end only: periodic in one frame once the receptive field away from both.
+// Output frame F depends on input frames [F - back, F + fwd] (api.hip, generator_frame_dependence).
+//   gen_plan:  glen[b] = len[b] + back + 1 + fwd where that is < T (else T): the frames the generator computes for b;
+//   gen_tail_fill:  frames [len + back + 1, T - fwd) of o[b] = frame len + back (the steady state), frames
+//                   [T - fwd, T) = frames [len + back + 1, len + back + 1 + fwd) (the computed tensor end); up = samples per frame.
+hipError_t launch_gen_plan(const int64_t* lengths, int B, int T, int back, int fwd, int* glen, hipStream_t s);
+hipError_t launch_gen_tail_fill(float* o, long o_bs, const int64_t* lengths, const int* glen, int B, int T, int back, int fwd,
+                                int up, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------
 // attention with windowed relative position (reference attentions.py:148-179), f32 MFMA.
