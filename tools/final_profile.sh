@@ -26,5 +26,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace_c5" -o t -- py
 rocprofv3 --kernel-trace --output-format csv -d "$O/trace_one" -o t -- python3 "$R/bench.py" --workload C2 --batch 1 --steps 4 --warmup 2 --profile-steps 0 --no-cpu-baseline > /dev/null 2>> "$O/bench.err" || true
 python3 "$R/tools/trace_timeline.py" "$O/trace_one/t_kernel_trace.csv" > "$O/one_utterance_timeline.txt" || true
 python3 "$R/tools/trace_timeline.py" "$O/trace_c5/t_kernel_trace.csv" > "$O/c5_timeline.txt" || true
+# round 5: the per-rank operating points of the strong-scaling metric (rank 0's slice at N = 1 / 2 / 4 / 8, global padding)
+# and the trimmed-tails switch, same box
+for N in 1 2 4 8; do
+  python3 "$R/bench.py" --shard-of $N --shard-rank 0 --steps 20 --warmup 4 --no-cpu-baseline > "$O/bench_shard_of_$N.json" 2>> "$O/bench.err" || true
+done
+VSP_TRIM_TAILS=0 python3 "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline > "$O/bench_untrimmed.json" 2>> "$O/bench.err" || true
 rm -f "$O"/trace*/t_kernel_trace.csv "$O"/pmc_*/p_agent_info.csv
 cat "$O/pytest_gpu.txt"; cut -c1-300 "$O/bench.json"; tail -3 "$O/generator_per_launch.txt"; cat "$O/traffic.json"

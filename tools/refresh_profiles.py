@@ -42,6 +42,32 @@ for f, k in (("bench_c2", "C2"), ("bench_c5", "C5"), ("bench_controls_duration",
         out[k]["generator_ms_per_step"] = x["roofline"]["kernel_ms_per_step"]
     print(k, round(x["ms_per_step"], 2), "ms", round(x["value"] / 1e6, 1), "M samples/s")
 json.dump(out, open(os.path.join(P, f"{tag}_other_workloads.json"), "w"), indent=1)
+# round 5: per-rank operating points (bench.py --shard-of N: rank 0's shard_range slice under the global padding) and the
+# untrimmed second implementation, same box as the headline line
+ops = {}
+for N in (1, 2, 4, 8):
+    path = os.path.join(F, f"bench_shard_of_{N}.json")
+    if os.path.exists(path):
+        x = json.loads(open(path).read().strip().splitlines()[-1]); r = x["roofline"]
+        ops[f"N={N}"] = {"utterances_per_gpu": x["config"]["utterances_per_gpu"], "padded_frames": x["config"]["padded_frames"],
+                         "ms_per_step": x["ms_per_step"], "samples_per_s_per_gpu": x["value"],
+                         "generator_ms": r["kernel_ms_per_step"], "generator_launches": r["launches"],
+                         "attention_ms": r["attention"]["ms_per_step"], "frame_rate_convs_ms": r["frame_rate_convs"]["ms_per_step"],
+                         "frame_rate_launches": r["frame_rate_convs"]["launches"],
+                         "families_ms": (r.get("dominant_kernel") or {}).get("families_ms_per_step")}
+if ops:
+    base = ops.get("N=1", {}).get("samples_per_s_per_gpu")
+    for k, v in ops.items():
+        v["per_gpu_rate_vs_N1"] = v["samples_per_s_per_gpu"] / base if base else None
+        v["predicted_whole_job_samples_per_s"] = v["samples_per_s_per_gpu"] * int(k[2:])   # (before the gather: an upper bound)
+    path = os.path.join(F, "bench_untrimmed.json")
+    if os.path.exists(path):
+        x = json.loads(open(path).read().strip().splitlines()[-1])
+        ops["untrimmed_N=1 (VSP_TRIM_TAILS=0)"] = {"ms_per_step": x["ms_per_step"], "samples_per_s": x["value"],
+                                                   "generator_ms": x["roofline"]["kernel_ms_per_step"]}
+    json.dump(ops, open(os.path.join(P, f"{tag}_per_rank_operating_points.json"), "w"), indent=1)
+    for k, v in ops.items():
+        print(k, {kk: (round(vv, 3) if isinstance(vv, float) else vv) for kk, vv in v.items() if kk != "families_ms"})
 d = json.loads(open(os.path.join(F, "bench.json")).read().strip().splitlines()[-1])
 r = d["roofline"]
 print("C3", round(d["ms_per_step"], 2), "ms", round(d["value"] / 1e6, 1), "M;",
