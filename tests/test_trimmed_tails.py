@@ -136,6 +136,26 @@ def test_trimmed_tails_under_every_kernel_selection(net_untrimmed, weights, monk
     np.testing.assert_array_equal(to_np(run(two, b)[0]), to_np(run(net_untrimmed, b)[0]))
 
 
+def test_trimmed_tails_in_the_reduced_precision_mode(weights, monkeypatch):
+    """VSP_GENERATOR=f16 (opt-in, one MFMA per product) runs the same kernels with TERMS = 1: trimmed == untrimmed there
+    too."""
+    monkeypatch.setenv("VSP_GENERATOR", "f16")
+    a = make_net(weights)
+    monkeypatch.setenv("VSP_TRIM_TAILS", "0")
+    c = make_net(weights)
+    b = batch_with_frames([90, 40, 61, 12], seed=506)
+    np.testing.assert_array_equal(to_np(run(a, b)[0]), to_np(run(c, b)[0]))
+
+
+def test_trimmed_tails_zero_length_and_single_utterance(net, net_untrimmed):
+    """An utterance of zero frames (all durations zero) inside a batch is all padding: its whole waveform is the
+    steady state + the tensor end; a batch of one has nothing to trim."""
+    b = batch_with_frames([64, 0, 33], seed=507)
+    np.testing.assert_array_equal(to_np(run(net, b)[0]), to_np(run(net_untrimmed, b)[0]))
+    b1 = batch_with_frames([50], seed=508)
+    np.testing.assert_array_equal(to_np(run(net, b1)[0]), to_np(run(net_untrimmed, b1)[0]))
+
+
 def test_trimmed_tails_with_max_len_and_global_padding(net, net_untrimmed):
     """max_len cuts the frame axis in front of the vocoder (models.py:720): lengths beyond the cut are untrimmed; a
     global padding t_f (sharded batches) beyond the local maximum makes EVERY utterance a trimmed one."""
