@@ -148,6 +148,31 @@ def test_cl_resblock_persistent_pair_kernel_long_rows(lib, k, dils, b, t):
     assert rel_err(outs[1].numpy(), torch_resblock(x, ws, bs, dils, k)) <= TOL
 
 
+@pytest.mark.parametrize("dils", [(1, 3, 5), (5,), (2, 4)])
+@pytest.mark.parametrize("b,t", [(3, 40000), (1, 190000), (5, 777), (2, 94), (1, 95), (7, 1)])
+def test_cl_resblock_register_weights_pair_64_channels(lib, dils, b, t, monkeypatch):
+    """g16_rw64 (gen16_rw64.hip, round 5; opt-in, VSP_RW64=1: measured slower than the ring kernel): the kernel-3 pairs of
+    the 64-channel stage with the weights in registers, persistent blocks walking runs of 94-column tiles that cross
+    utterance boundaries -- bit for bit against the per-convolution path, and against torch's fp64 convolution."""
+    monkeypatch.setenv("VSP_RW64", "1")
+    c, k = 64, 3
+    r = np.random.Generator(np.random.PCG64(64 * 31 + t + len(dils)))
+    x = r.standard_normal((b, t, c)).astype(np.float32)
+    ws = [(r.standard_normal((c, c, k)) / np.sqrt(c * k)).astype(np.float32) for _ in range(2 * len(dils))]
+    bs = [r.standard_normal(c).astype(np.float32) * 0.1 for _ in range(2 * len(dils))]
+    xd = torch.from_numpy(x).cuda()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    darr = (C.c_int * len(dils))(*dils)
+    outs = []
+    for mode in (0, 1):
+        out = torch.full((b, t, c), float("nan"), device="cuda")
+        rc = lib.vsp_cl_resblock(stream, b, t, c, k, len(dils), darr, P(xd), host_ptrs(ws), host_ptrs(bs), mode, 3, P(out))
+        assert rc == 0, mode
+        outs.append(out.cpu())
+    assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
+    assert rel_err(outs[1].numpy(), torch_resblock(x, ws, bs, dils, k)) <= TOL
+
+
 @pytest.mark.parametrize("k,dils,mode", [(7, (1, 3), 1), (11, (5,), 1), (3, (1, 3, 5), 2)])
 def test_persistent_kernels_beyond_256_utterances(lib, k, dils, mode):
     """A tile cursor of the persistent kernels (g16_rw, g16_rc) keeps the utterance in 8 bits next to its extent

@@ -458,10 +458,11 @@ def test_reduced_precision_mode_is_opt_in_and_gated(dims, weights, golden_dir, m
 
 @pytest.mark.parametrize("env", [{"VSP_FUSE_PAIRS": "0"}, {"VSP_CHAIN": "0"}, {"VSP_CHAIN": "7"}, {"VSP_PAIR": "ring"},
                                  {"VSP_TIMG": "0"}, {"VSP_FUSE_PAIRS": "0", "VSP_TIMG": "0"}, {"VSP_PP": "0"},
-                                 {"VSP_PP": "0", "VSP_TIMG": "0"}, {"VSP_CHAIN_RING": "1"}],
+                                 {"VSP_PP": "0", "VSP_TIMG": "0"}, {"VSP_CHAIN_RING": "1"}, {"VSP_RW64": "1"}],
                          ids=["two_launches", "pair_launches", "chains_for_every_kernel_size", "ring_pair_kernel",
                               "fp32_intermediates", "two_launches_fp32_intermediates", "no_128_channel_pair_kernel",
-                              "no_128_channel_pair_kernel_fp32_intermediates", "ring_chain_kernel"])
+                              "no_128_channel_pair_kernel_fp32_intermediates", "ring_chain_kernel",
+                              "register_weights_k3_pairs_64_channels"])
 def test_fused_resblock_paths_are_bit_identical(net, dims, weights, monkeypatch, env):
     """The ResBlocks of the 32/64-channel stages run fused (gen16.hip): by default a whole ResBlock of the
     32-channel stage is ONE launch (g16_chain: the running x in registers, every intermediate in LDS, the chain's halo

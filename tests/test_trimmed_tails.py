@@ -125,6 +125,7 @@ def test_trimmed_tail_structure(net_untrimmed):
     {"VSP_FUSE_PAIRS": "0"},                     # one g16_conv launch per convolution everywhere
     {"VSP_TIMG": "0", "VSP_PP": "0"},            # fp32 intermediates, two-launch pairs at 128 channels
     {"VSP_CHAIN": "7"},                          # whole-ResBlock launches for k3, k7 and k11
+    {"VSP_RW64": "1"},                           # the 64-channel k3 pairs on the register-weights kernel (opt-in)
 ], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_trimmed_tails_under_every_kernel_selection(net_untrimmed, weights, monkeypatch, env):
     """Every generator kernel has the per-utterance extent: the second implementations, trimmed, equal the default

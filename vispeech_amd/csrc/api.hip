@@ -205,6 +205,7 @@ struct Run {
     a.acc_prev = acc_prev ? 1 : 0; a.div = div;
     a.terms = ctx->gen_mode == 2 ? 1 : 3;
     a.ring = ctx->pair_ring ? 1 : 0;
+    a.rw64 = ctx->rw64 ? 1 : 0;
     a.glen = glen; a.grate = grate_out;
     const bool prof = prof_begin(VSP_PROF_GENERATOR, fam(VSP_FAM_PAIR, L1.Cout));
     chk(launch_g16_pair(a, B, s), "g16_pair");
@@ -661,6 +662,7 @@ int vsp_create(const vsp_config* cfg, int device, vsp_ctx** out) {
   if (const char* e = getenv("VSP_PAIR")) ctx->pair_ring = !strcmp(e, "ring");
   if (const char* e = getenv("VSP_CHAIN_RING")) ctx->chain_ring = atoi(e) != 0;
   if (const char* e = getenv("VSP_CHAIN")) ctx->chain_mask = atoi(e);
+  if (const char* e = getenv("VSP_RW64")) ctx->rw64 = atoi(e) != 0;               // 1: g16_rw64 for the 64-channel k3 pairs (opt-in)
   if (const char* e = getenv("VSP_TRIM_TAILS")) ctx->trim_tails = atoi(e) != 0;   // 0: every utterance runs to the padded length
 #ifdef VSP_EXPERIMENTS
   if (const char* e = getenv("VSP_ATT_KSPLIT")) ctx->att_ksplit = atoi(e);
@@ -1780,6 +1782,7 @@ int vsp_cl_resblock(void* stream, int B, int T, int C, int K, int n_pairs, const
         a.b1 = static_cast<const float*>(bias[2 * p].p); a.b2 = static_cast<const float*>(bias[2 * p + 1].p);
         a.C = C; a.K = K; a.dil = dilations[p]; a.T = T; a.slope = 0.1f; a.acc_prev = 0; a.div = 1.f; a.terms = terms;
         if (const char* ev = getenv("VSP_PAIR")) a.ring = !strcmp(ev, "ring");     // (read per call: the test API has no context)
+        if (const char* ev = getenv("VSP_RW64")) a.rw64 = atoi(ev) != 0;
         e = launch_g16_pair(a, B, s);
       } else {
         // one launch per convolution; the intermediate as an operand image where the kernels take one (terms 3, K >= 3):

@@ -974,6 +974,9 @@ hipError_t launch_g16_pair(const ClPairArgs& a, int B, hipStream_t s) {
   // round 4: weights in registers, persistent blocks (gen16_rw.hip) where that kernel exists; ClPairArgs::ring (VSP_PAIR=ring) keeps the
   // LDS-ring kernel below (the second implementation under test: bit-identical)
   if (!a.ring && g16_rw_supported(a.C, a.K, a.dil, a.terms)) return launch_g16_rw(a, B, s);
+  // round 5: the same for the kernel-3 pairs of the 64-channel stage (gen16_rw64.hip) -- bit-identical, measured 2-5 % SLOWER
+  // than the ring kernel below (profiles/r05_g16_rw64_k3_pairs_64_channels.txt): opt-in (ClPairArgs::rw64, VSP_RW64=1)
+  if (!a.ring && a.rw64 && g16_rw64_supported(a.C, a.K, a.dil, a.terms)) return launch_g16_rw64(a, B, s);
   if (a.terms == 1)
     return a.C == 32 ? launch_g16_pair_tile<1, 2, 1, 8>(a, B, s) : launch_g16_pair_tile<2, 1, 1, 8>(a, B, s);
   // round 3: TWO ring slots of twice the taps (32 channels: 4 taps = 16 KB, 64 channels: 2 taps = 16 KB; 72 KB of LDS

@@ -113,6 +113,7 @@ struct ClPairArgs {
   int acc_prev; float div;                  // out = (result + out) / div
   int terms;                                // 3 = split product, 1 = plain f16 operands
   int ring;                                 // 1: the LDS-ring pair kernel (g16_pair) even where the register-weights one exists
+  int rw64;                                 // 1: the register-weights kernel for 64-channel kernel-3 pairs (g16_rw64; opt-in, VSP_RW64=1)
   int tiles;                                // set by the launcher: tiles per utterance
   int xrows;                                // set by the launcher: staged window rows
   const int* glen; int grate;               // ragged batch (see ClConvArgs): utterance b's T = glen[b] * grate; NULL = uniform
@@ -152,6 +153,9 @@ hipError_t launch_g16_pair(const ClPairArgs& a, int B, hipStream_t s);
 // launch_g16_pair routes there unless ClPairArgs::ring (VSP_PAIR=ring) asks for the LDS-ring kernel (second implementation, bit-identical)
 bool g16_rw_supported(int C, int K, int dil, int terms);
 hipError_t launch_g16_rw(const ClPairArgs& a, int B, hipStream_t s);
+// ... and the kernel-3 pairs of the 64-channel stage (gen16_rw64.hip, round 5: two row halves x two column halves per role)
+bool g16_rw64_supported(int C, int K, int dil, int terms);
+hipError_t launch_g16_rw64(const ClPairArgs& a, int B, hipStream_t s);
 // the pair of the 128-channel stage on the ping-pong tile, kernel 3 / 7 (gen16_pp.hip); VSP_PP=0 (read per context): two launches (bit-identical)
 bool g16_pp_supported(int C, int K, int dil, int terms);
 hipError_t launch_g16_pp(const ClPairArgs& a, int B, hipStream_t s);

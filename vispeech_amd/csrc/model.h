@@ -117,6 +117,7 @@ struct vsp_ctx {
   bool pp_pairs = true;           // k3 / k7 conv pairs of the 128-channel stage as one launch (g16_pp; VSP_PP=0: two launches)
   bool pair_ring = false;         // VSP_PAIR=ring: the LDS-ring pair kernel on the 32-channel stage instead of g16_rw
   bool chain_ring = false;        // VSP_CHAIN_RING=1: the LDS-ring chain kernel (g16_chain) instead of g16_rc
+  bool rw64 = false;              // VSP_RW64=1: the 64-channel k3 pairs on g16_rw64 (register weights; measured slower: opt-in)
   bool trim_tails = true;         // ragged batches: the generator runs each utterance to length + 2 halo + 1 frames and fills the
                                   // padded tail from the steady state (VSP_TRIM_TAILS=0: to the padded length; bit-identical)
   int64_t noise_first = 0;        // stream index of element 0 of a library-drawn noise tensor (vsp_set_noise_offset)
