@@ -1456,6 +1456,17 @@ static long fr_max_blocks() {
 #endif
 }
 
+// (round 5 experiment: a separate limit for 1x1 convolutions, whose throughput-kernel blocks are chains of window round trips)
+static long fr_max_blocks_k1() {
+#ifdef VSP_EXPERIMENTS
+  static long v = -1;
+  if (v < 0) { const char* e = getenv("VSP_FR_BLOCKS_K1"); v = e ? atol(e) : fr_max_blocks(); }
+  return v;
+#else
+  return fr_max_blocks();
+#endif
+}
+
 // Grids up to this many 64 x 32 tiles take the channel-split kernel (same box: one utterance 5.17 -> 3.9 ms, the
 // 5168-frame utterance 18.4 -> 17.8, C2 24.5 -> 24.1; thresholds 128 / 256 / 512 / 1024 / 4096 swept).
 static long fr_splitk_blocks() {
@@ -1505,7 +1516,7 @@ hipError_t launch_conv(const ConvArgs& a, int B, hipStream_t s) {
         // tests compare generator outputs of different lengths bit for bit)
       }
       if (a.Nq <= 96) { if (blocks * 2 <= fr_max_blocks() && launch_frame_k<2, 1, 1, 2>(a, B, s, e)) return e; }
-      else if (blocks <= fr_max_blocks()) { if (launch_frame_k<2, 1, 1, 4>(a, B, s, e)) return e; }
+      else if (blocks <= (a.K == 1 ? fr_max_blocks_k1() : fr_max_blocks())) { if (launch_frame_k<2, 1, 1, 4>(a, B, s, e)) return e; }
     }
     if (a.M <= 32 && !gate) {
       if (a.Nq >= 1024) return launch_tile<1, 4, 1, 4, true, true>(a, B, s);
