@@ -157,6 +157,21 @@ def test_trimmed_tails_zero_length_and_single_utterance(net, net_untrimmed):
     np.testing.assert_array_equal(to_np(run(net, b1)[0]), to_np(run(net_untrimmed, b1)[0]))
 
 
+@pytest.mark.parametrize("seed", [601, 602, 603, 604])
+def test_trimmed_tails_random_batches(net, net_untrimmed, seed):
+    """Random batch sizes and lengths (tile boundaries of every generator kernel land anywhere relative to the
+    utterance ends): trimmed == untrimmed, bit for bit."""
+    r = np.random.Generator(np.random.PCG64(seed))
+    nb = int(r.integers(2, 12))
+    tmax = int(r.integers(60, 260))
+    frames = [int(x) for x in r.integers(1, tmax + 1, size=nb)]
+    frames[int(r.integers(0, nb))] = tmax
+    b = batch_with_frames(frames, seed=seed)
+    o1, o0 = to_np(run(net, b)[0]), to_np(run(net_untrimmed, b)[0])
+    for i, L in enumerate(frames):
+        np.testing.assert_array_equal(o1[i], o0[i], err_msg=f"seed {seed}: utterance {i} ({L} of {tmax} frames)")
+
+
 def test_trimmed_tails_with_max_len_and_global_padding(net, net_untrimmed):
     """max_len cuts the frame axis in front of the vocoder (models.py:720): lengths beyond the cut are untrimmed; a
     global padding t_f (sharded batches) beyond the local maximum makes EVERY utterance a trimmed one."""

@@ -32,5 +32,6 @@ for N in 1 2 4 8; do
   python3 "$R/bench.py" --shard-of $N --shard-rank 0 --steps 20 --warmup 4 --no-cpu-baseline > "$O/bench_shard_of_$N.json" 2>> "$O/bench.err" || true
 done
 VSP_TRIM_TAILS=0 python3 "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline > "$O/bench_untrimmed.json" 2>> "$O/bench.err" || true
+python3 "$R/bench.py" --workload C4 --steps 5 --warmup 2 --cpu-sample 2 --cpu-runs 1 > "$O/bench_c4.json" 2>> "$O/bench.err" || true
 rm -f "$O"/trace*/t_kernel_trace.csv "$O"/pmc_*/p_agent_info.csv
 cat "$O/pytest_gpu.txt"; cut -c1-300 "$O/bench.json"; tail -3 "$O/generator_per_launch.txt"; cat "$O/traffic.json"

@@ -26,7 +26,8 @@ shutil.copy(os.path.join(F, "traffic.json"), os.path.join(P, "traffic.json"))
 out = {}
 for f, k in (("bench_c2", "C2"), ("bench_c5", "C5"), ("bench_controls_duration", "C3_duration_supplied_F0_energy_predicted"),
              ("bench_controls_none", "C3_all_predictors_on"), ("bench_f16mode", "C3_f16_reduced_precision_mode"),
-             ("bench_traced", "C3_under_rocprofv3_trace"), ("bench_one_utterance", "one_utterance_latency")):
+             ("bench_traced", "C3_under_rocprofv3_trace"), ("bench_one_utterance", "one_utterance_latency"),
+             ("bench_c4", "C4_256_utterances_on_one_gpu")):
     path = os.path.join(F, f + ".json")
     if not os.path.exists(path):
         continue

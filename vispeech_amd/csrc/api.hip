@@ -15,6 +15,7 @@ using namespace vsp;
 namespace {
 
 void generator_frame_dependence(const vsp_config& c, int pre_k, int post_k, int& back, int& fwd);   // (defined below)
+long total_upsample(const vsp_config& c);
 
 struct T3 {
   float* p = nullptr;
@@ -488,7 +489,8 @@ void run_generator_cl(Run& r, int B, int T, T3 z, const int64_t* in_lengths, con
   int back = 0, fwd = 0;
   generator_frame_dependence(c, m.g_pre.K, m.post_k, back, fwd);
   int* glen_all = r.ctx->trim_tails ? reinterpret_cast<int*>(r.ws.bytes((size_t)B * sizeof(int))) : nullptr;
-  const bool trim = glen_all && in_lengths && T > back + fwd + 1;
+  // (gen_tail_fill keeps the computed tensor end -- fwd frames of the waveform -- in 64 KB of LDS: other configurations run untrimmed)
+  const bool trim = glen_all && in_lengths && T > back + fwd + 1 && (size_t)fwd * total_upsample(c) * sizeof(float) <= 64 * 1024;
   if (trim && !r.dry() && r.ok()) r.chk(launch_gen_plan(in_lengths, B, T, back, fwd, glen_all, r.s), "gen_plan");
   // the channels-last kernels address one utterance's tensor with 32-bit byte offsets (buffer descriptors)
   // (the operand images -- C * 4 * (T + 384) bytes per utterance -- are addressed the same way)
