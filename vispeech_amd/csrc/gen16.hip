@@ -80,7 +80,13 @@ __device__ __forceinline__ float* g16_out_base(const ClConvArgs& a, int b) {
 // copies one (image, plane) of it in NL pieces of 64 rows -- with no conversion arithmetic, no staging registers and,
 // above all, without the vmcnt(0) hipcc puts in front of the staged registers' first use, which drained the weight ring
 // once per chunk.  The same arithmetic on the same bits: results are bit-identical to the fp32-input form.
-template <int MW, int NW, int WM, int WN, int TERMS, bool XIN = false>
+#ifndef G16_EPI_LDS
+#define G16_EPI_LDS 1
+#endif
+#ifndef G16_IMG_EPI
+#define G16_IMG_EPI 1
+#endif
+template <int MW, int NW, int WM, int WN, int TERMS, bool XIN = false, bool IMG_EPI = false>
 __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
   constexpr int NWV = WM * WN, NTH = 64 * NWV;
   constexpr int BT = 16 * NW * WN;              // time columns per block
@@ -327,6 +333,100 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
   // (the first half of the block has executed one barrier fewer: it goes straight to its epilogue, which overlaps
   // the second half's last MFMA phase; a wave that has ended no longer takes part in the barrier)
 
+  // ... and for the image-only results (a ResBlock pair's intermediate): the activated, split tile goes to the LDS in the
+  //      image's own plane layout [chunk][hi | lo][plane][column][8 halfs], then a wave copies whole planes -- 64 consecutive
+  //      time rows of one plane = 1 KiB contiguous per b128 store, sixteen per wave instead of thirty-two b64 stores of two
+  //      256-byte segments each.  The same split of the same values: bit-identical images.
+  // (its own instantiation, IMG_EPI -- picked by the launcher for exactly these launches: as a third path inside the one
+  // kernel it cost 35-40 spilled registers)
+  if constexpr (IMG_EPI) {
+    static_assert(G16_EPI_LDS && TERMS == 3 && MTB == 8 && BT == 256 && NWV == 8, "the 128-row x 256-column tile");
+    constexpr int EPL = BT * 16;                    // bytes of one plane of the tile in the LDS
+    static_assert((size_t)32 * EPL <= (size_t)2 * XBUF + (size_t)NS * SLOT, "the image tile fits the dead window + ring");
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+      for (int j = 0; j < NW; ++j) {
+        f32x4 v = hh[i][j] + cr[i][j] * (1.f / 2048.f);
+        g16_div(v, a.div);
+        f16x4 eh, el;
+        g16_split4(v, a.oi_slope, true, eh, el);
+        const int mt = wm * MW + i, col = (wn * NW + j) * 16 + (lane & 15), q4e = lane >> 4;
+        char* dst = lds + (((mt >> 1) * 2) * 4 + 2 * (mt & 1) + (q4e >> 1)) * EPL + col * 16 + 8 * (q4e & 1);
+        *reinterpret_cast<f16x4*>(dst) = eh;
+        *reinterpret_cast<f16x4*>(dst + 4 * EPL) = el;
+        __builtin_amdgcn_sched_barrier(0);            // (a tile at a time: sixteen splits in flight at once cost spills)
+      }
+    G16_BARRIER();
+    const __amdgpu_buffer_rsrc_t ri2 = __builtin_amdgcn_make_buffer_rsrc(a.o_img + (size_t)b * a.oi_bs, 0, a.Cout * 4 * a.oi_tpad, 0x00020000);
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      __builtin_amdgcn_sched_barrier(0);              // (a plane at a time: the copies of all sixteen pieces at once cost spills)
+      const int p = wave * 4 + pp;                    // plane of the tile: (chunk of the block, hi | lo, plane)
+      const int gplane = (cb * 4 + (p >> 3)) * 8 + (p & 7);
+#pragma unroll
+      for (int u = 0; u < BT / 64; ++u) {
+        const int col = 64 * u + lane, t = t0 + col;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(lds + p * EPL + col * 16);
+        const int off = t < Nq ? (gplane * a.oi_tpad + G16_IMG_PADF + t) * 16 : G16_OOR;
+        __builtin_amdgcn_raw_buffer_store_b128(v, ri2, off, 0, 0);
+      }
+    }
+  } else {
+  // ---- epilogue through the LDS (round 5) for the plain fp32 destinations (no polyphase scatter, no operand image): in
+  //      the D-tile layout a b128 access of a wave is 16 rows x 64 B -- sixteen half-line segments per instruction, and with
+  //      one block per CU nothing hides the residual round trip and the store issue (2.8-3.8 us per tile by the stamps of
+  //      round 4).  The tile (cross accumulator folded) goes to the dead window / ring as [column][block's channels] fp32
+  //      (+ 16 B per column: conflict-free 16-byte writes), then a wave owns whole columns: RB / 4 lanes x 16 B = one
+  //      column's channels, contiguous in the channels-last tensor -- residual, previous sum and result alike.  The same
+  //      arithmetic in the same order as below: bit-identical.  Nobody reads the LDS any more: the first half has passed
+  //      the barrier behind its last MFMA phase, which the second half reached only after its last fragment reads.
+  constexpr int RB = 16 * MTB, ECS = RB * 4 + 16, LPC = RB / 4, CPI = 64 / LPC, NIT = BT / CPI / NWV;
+  // (the 128-row tile only: the 64- / 32-row tiles of under-filled grids keep the direct form -- there the compiler spills)
+  constexpr bool EPI_LDS_FITS = MTB == 8 && (size_t)BT * ECS <= (size_t)2 * XBUF + (size_t)NS * SLOT && BT % (CPI * NWV) == 0;
+  if constexpr (G16_EPI_LDS && EPI_LDS_FITS) if (a.phases == 1 && a.out && !a.o_img) {
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+      for (int j = 0; j < NW; ++j) {
+        f32x4 v = hh[i][j];
+        if constexpr (TERMS == 3) v += cr[i][j] * (1.f / 2048.f);
+        const int col = (wn * NW + j) * 16 + (lane & 15);
+        *reinterpret_cast<f32x4*>(lds + col * ECS + ((wm * MW + i) * 16 + 4 * (lane >> 4)) * 4) = v;
+      }
+    G16_BARRIER();
+    const int lc = lane % LPC, cw = lane / LPC;
+    // (in batches of at most eight accesses per lane: the operands of a batch are in flight together)
+    constexpr int NBT = NIT > 8 ? 8 : NIT;
+    static_assert(NIT % NBT == 0, "whole batches");
+#pragma unroll
+    for (int u0 = 0; u0 < NIT; u0 += NBT) {
+      int eo[NBT];
+      u32x4 rv[NBT];
+      [[maybe_unused]] u32x4 pv[NBT];
+#pragma unroll
+      for (int u = 0; u < NBT; ++u) {
+        const int t = t0 + (wave * NIT + u0 + u) * CPI + cw;
+        const bool in_t = t < Nq && (G16_DIAG & 8) == 0;
+        eo[u] = in_t ? (t * a.o_ts + cb * RB + 4 * lc) * 4 : G16_OOR;
+        if (a.res) rv[u] = __builtin_amdgcn_raw_buffer_load_b128(rr_, in_t ? (t * a.r_ts + cb * RB + 4 * lc) * 4 : G16_OOR, 0, 0);
+      }
+      if (a.acc_prev) {
+#pragma unroll
+        for (int u = 0; u < NBT; ++u) pv[u] = __builtin_amdgcn_raw_buffer_load_b128(ro, eo[u], 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < NBT; ++u) {
+        const int col = (wave * NIT + u0 + u) * CPI + cw;
+        f32x4 v = *reinterpret_cast<const f32x4*>(lds + col * ECS + lc * 16);
+        if (a.res) v += g16_as_f32x4(rv[u]);
+        if (a.acc_prev) v += g16_as_f32x4(pv[u]);
+        g16_div(v, a.div);
+        __builtin_amdgcn_raw_buffer_store_b128(g16_as_u32x4(v), ro, eo[u], 0, 0);
+      }
+    }
+    return;
+  }
   // ---- epilogue: lane = 4 consecutive rows (channels) of one time column: 16-byte accesses.  All residual /
   //      accumulate operands of the wave's tiles are requested first (the fragment registers are dead now).
   G16_STAMP();                                              // epilogue start
@@ -401,6 +501,7 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   G16_STAMP();                                              // stores retired
 #endif
+  }
 }
 
 #ifdef G16_STAMPS
@@ -416,13 +517,13 @@ extern "C" int vsp_debug_stamps_g16(unsigned long long* host, int max_samples, i
 }
 #endif
 
-template <int MW, int NW, int WM, int WN, int TERMS, bool XIN = false>
+template <int MW, int NW, int WM, int WN, int TERMS, bool XIN = false, bool IMG_EPI = false>
 static hipError_t launch_g16_tile(const ClConvArgs& a, int B, hipStream_t s) {
   constexpr int BT = 16 * NW * WN, MTB = MW * WM;
   constexpr size_t lds = (size_t)2 * 2 * 4 * (BT + G16_HALO) * 16 + (size_t)4 * MTB * 2048;
   static_assert(lds <= 160 * 1024, "LDS budget");
   static std::atomic<uint64_t> attr_done{0};
-  auto kern = g16_conv<MW, NW, WM, WN, TERMS, XIN>;
+  auto kern = g16_conv<MW, NW, WM, WN, TERMS, XIN, IMG_EPI>;
   if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, attr_done); e != hipSuccess) return e;
   const int nmt = a.phases * a.Cout / 16;
   if (nmt % MTB || a.Cin % 32) return hipErrorInvalidValue;
@@ -619,6 +720,10 @@ hipError_t launch_g16_conv(const ClConvArgs& a, int B, hipStream_t s) {
     if (rows % 32 == 0) return launch_g16_tile<2, 2, 1, 8, 3, true>(a, B, s);
     return hipErrorInvalidValue;
   }
+  // (an image-only result -- a ResBlock pair's intermediate -- of the 128-row tile: the instantiation whose epilogue goes
+  // through the LDS, 1 KiB contiguous per store; bit-identical images)
+  if (G16_EPI_LDS && G16_IMG_EPI && rows % 128 == 0 && want >= 128 && a.phases == 1 && !a.out && a.o_img && !a.res && !a.acc_prev)
+    return launch_g16_tile<4, 4, 2, 4, 3, false, true>(a, B, s);
   if (rows % 128 == 0 && want >= 128) return launch_g16_tile<4, 4, 2, 4, 3>(a, B, s);   // 128 rows x 256 columns, one block per CU
   if (rows % 64 == 0 && want >= 64) return launch_g16_tile<4, 2, 1, 8, 3>(a, B, s);     //  64 rows x 256 columns
   if (rows % 32 == 0) return launch_g16_tile<2, 2, 1, 8, 3>(a, B, s);                   //  32 rows x 256 columns
@@ -908,6 +1013,8 @@ __global__ void __launch_bounds__(64 * NWV, 4) g16_pair(ClPairArgs a) {
 
   // ---- epilogue: y = conv2 + x (+ previous resblock sum) (/ div); columns >= R2 belong to the next tile
   G16_STAMPT(30);
+  // (round 5: the through-the-LDS form of g16_conv / g16_pp measured +-0 here -- two resident blocks per CU already hide
+  // the epilogue's round trips -- and cost 4 more spilled registers: profiles/r05_coalesced_epilogues.txt)
 #pragma unroll
   for (int i = 0; i < MW; ++i)
 #pragma unroll

@@ -58,6 +58,9 @@ extern "C" int vsp_debug_stamps_pp(unsigned long long* host) {
 #define PP_STAMP(tag) ((void)0)
 #endif
 
+#ifndef PP_EPI_LDS
+#define PP_EPI_LDS 1
+#endif
 template <int NW, int HALO>
 __global__ void __launch_bounds__(512) g16_pp(ClPairArgs a) {
   constexpr int NCH = 4, C = 32 * NCH, MW = 4, WN = 4, NWV = 8, MTB = 8;
@@ -303,6 +306,54 @@ __global__ void __launch_bounds__(512) g16_pp(ClPairArgs a) {
 
   // ---- epilogue: y = conv2 + x (+ previous resblock sum) (/ div); columns >= R2 belong to the next tile
   PP_STAMP(30);
+#if PP_EPI_LDS
+  // Round 5: through the LDS, so that every global access of the epilogue is 1 KiB CONTIGUOUS.  In the D-tile layout a lane
+  // holds four channels of one time row: a b128 load / store of a wave is 16 rows x 64 B -- sixteen half-line segments per
+  // instruction, and the stamps of round 4 showed the 12 stores of a wave taking 2.8-3.8 us to issue (one block per CU:
+  // nothing hides it).  The conv2 tile (cross accumulator folded) goes to the dead window as [column][128 channels] fp32
+  // (528-byte column stride: conflict-free 16-byte writes), then a wave owns whole column PAIRS: 32 lanes x 16 B = one
+  // column's 512 B, two adjacent columns = 1 KiB of the channels-last tensor -- residual, previous sum and result alike.
+  // Same arithmetic in the same order ((hh + cr / 2048) + x [+ previous] [/ div]): bit-identical.
+  // Nobody reads the window any more: the first half has passed the barrier behind its last MFMA phase, which the second
+  // half reached only after its last fragment reads.
+  constexpr int ECS = C * 4 + 16;                 // column stride in the LDS tile
+  static_assert(BT * ECS <= WIN, "the fp32 tile fits the dead window");
+#pragma unroll
+  for (int i = 0; i < MW; ++i)
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const f32x4 v = hh[i][j] + cr[i][j] * (1.f / 2048.f);
+      const int col = wn * NW * 16 + 16 * j + l15;
+      *reinterpret_cast<f32x4*>(Xw + col * ECS + (64 * wm + 16 * i + 4 * q4) * 4) = v;
+    }
+  G16_BARRIER();
+  {
+    constexpr int NPAIR = BT / 2 / NWV;           // column pairs per wave
+    const int half = lane >> 5, l31 = lane & 31;
+    int eo[NPAIR];
+    u32x4 rv[NPAIR];
+    [[maybe_unused]] u32x4 pv[NPAIR];
+#pragma unroll
+    for (int u = 0; u < NPAIR; ++u) {
+      const int col = 2 * (wave * NPAIR + u) + half;
+      eo[u] = (col < R2 && !(diag & 2)) ? ((t0 + col) * C + 4 * l31) * 4 : G16_OOR;   // (rows at and beyond T: out of the descriptor's range)
+      rv[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, (diag & 1) ? G16_OOR : eo[u], 0, 0);
+    }
+    if (a.acc_prev) {
+#pragma unroll
+      for (int u = 0; u < NPAIR; ++u) pv[u] = __builtin_amdgcn_raw_buffer_load_b128(ro, eo[u], 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < NPAIR; ++u) {
+      const int col = 2 * (wave * NPAIR + u) + half;
+      f32x4 v = *reinterpret_cast<const f32x4*>(Xw + col * ECS + l31 * 16);
+      v += g16_as_f32x4(rv[u]);
+      if (a.acc_prev) v += g16_as_f32x4(pv[u]);
+      g16_div(v, a.div);
+      __builtin_amdgcn_raw_buffer_store_b128(g16_as_u32x4(v), ro, eo[u], 0, 0);
+    }
+  }
+#else
   int oo[MW][NW];
 #pragma unroll
   for (int i = 0; i < MW; ++i)
@@ -346,6 +397,7 @@ __global__ void __launch_bounds__(512) g16_pp(ClPairArgs a) {
       g16_div(v, a.div);
       __builtin_amdgcn_raw_buffer_store_b128(g16_as_u32x4(v), ro, (diag & 2) ? G16_OOR : oo[i][j], 0, 0);
     }
+#endif
 #ifdef PP_STAMPS
   PP_STAMP(33);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
