@@ -86,6 +86,9 @@ __device__ __forceinline__ float* g16_out_base(const ClConvArgs& a, int b) {
 #ifndef G16_IMG_EPI
 #define G16_IMG_EPI 1
 #endif
+#ifndef G16_UPS_EPI_LDS
+#define G16_UPS_EPI_LDS 1
+#endif
 template <int MW, int NW, int WM, int WN, int TERMS, bool XIN = false, bool IMG_EPI = false>
 __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
   constexpr int NWV = WM * WN, NTH = 64 * NWV;
@@ -566,6 +569,9 @@ static bool g16_ups_on() {
 template <int KT, int NCH, int NMT, int ROLES>
 __global__ void __launch_bounds__(64 * (ROLES > 4 ? ROLES : 4)) g16_ups(ClConvArgs a, int tiles_per_wave) {
   constexpr int NWB = ROLES > 4 ? ROLES : 4;            // waves of a block
+#if G16_UPS_EPI_LDS
+  __shared__ __attribute__((aligned(16))) float ups_tile[NWB * 16 * (NMT * 16 + 4)];
+#endif
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kg = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int role = wave % ROLES, stream = wave / ROLES;
@@ -646,6 +652,34 @@ __global__ void __launch_bounds__(64 * (ROLES > 4 ? ROLES : 4)) g16_ups(ClConvAr
         }
       }
     // ---- store: lane = output row r (phase, channel), registers = four consecutive times q
+#if G16_UPS_EPI_LDS
+    // Round 5: through a wave-private LDS tile [q][the wave's rows r] (no barrier: a wave's LDS operations execute in
+    // order), read back as 16-byte pieces of four consecutive channels: a wave's store is then NMT * 64 contiguous bytes per
+    // input time (at stride 2 the tile's 32 output rows x 32 channels are ONE contiguous 4 KiB) instead of sixteen 4-byte
+    // stores of four 64-byte segments each.  Same values.
+    {
+      constexpr int RSF = NMT * 16 + 4;                       // floats per LDS row (+ 16 B: conflict-free 4-byte writes)
+      constexpr int CPR = NMT * 4;                            // 16-byte pieces per row
+      constexpr int RPI = 64 / CPR;                           // rows (input times) per b128 instruction
+      static_assert(64 % CPR == 0 && 16 % RPI == 0, "whole rows per instruction");
+      float* const et = ups_tile + wave * 16 * RSF;
+#pragma unroll
+      for (int m = 0; m < NMT; ++m)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+          et[(4 * kg + jj) * RSF + m * 16 + l15] = hh[m][jj] + cr[m][jj] * (1.f / 2048.f) + bv[m];
+      const int pc = lane % CPR, ql = lane / CPR;
+      const int r = mt0 * 16 + 4 * pc;                         // the piece's first row: four consecutive channels of one phase
+      const int ph = r / a.Cout, co = r - ph * a.Cout;
+#pragma unroll
+      for (int u = 0; u < 16 / RPI; ++u) {
+        const int qq = u * RPI + ql, q = q0 + qq;
+        const int n = a.phases * q + ph - a.ups_p;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(et + qq * RSF + 4 * pc);
+        if (q < Nq && n >= 0 && n < T_store) *reinterpret_cast<f32x4*>(ob + (size_t)n * a.o_ts + co) = v;
+      }
+    }
+#else
 #pragma unroll
     for (int m = 0; m < NMT; ++m)
 #pragma unroll
@@ -655,6 +689,7 @@ __global__ void __launch_bounds__(64 * (ROLES > 4 ? ROLES : 4)) g16_ups(ClConvAr
         if (q < Nq && n >= 0 && n < T_store)
           ob[(size_t)n * a.o_ts + co_of[m]] = hh[m][jj] + cr[m][jj] * (1.f / 2048.f) + bv[m];
       }
+#endif
   }
 }
 
@@ -722,8 +757,10 @@ hipError_t launch_g16_conv(const ClConvArgs& a, int B, hipStream_t s) {
   }
   // (an image-only result -- a ResBlock pair's intermediate -- of the 128-row tile: the instantiation whose epilogue goes
   // through the LDS, 1 KiB contiguous per store; bit-identical images)
-  if (G16_EPI_LDS && G16_IMG_EPI && rows % 128 == 0 && want >= 128 && a.phases == 1 && !a.out && a.o_img && !a.res && !a.acc_prev)
+#if G16_EPI_LDS && G16_IMG_EPI
+  if (rows % 128 == 0 && want >= 128 && a.phases == 1 && !a.out && a.o_img && !a.res && !a.acc_prev)
     return launch_g16_tile<4, 4, 2, 4, 3, false, true>(a, B, s);
+#endif
   if (rows % 128 == 0 && want >= 128) return launch_g16_tile<4, 4, 2, 4, 3>(a, B, s);   // 128 rows x 256 columns, one block per CU
   if (rows % 64 == 0 && want >= 64) return launch_g16_tile<4, 2, 1, 8, 3>(a, B, s);     //  64 rows x 256 columns
   if (rows % 32 == 0) return launch_g16_tile<2, 2, 1, 8, 3>(a, B, s);                   //  32 rows x 256 columns
