@@ -227,6 +227,13 @@ int vsp_generator(vsp_ctx* ctx, void* stream, int B, int T, const float* z, cons
  * o_chunk [B][1][(f1 - f0) * prod(upsample_rates)] contiguous; workspace >= vsp_generator_stream_workspace_bytes
  * for the largest f1 - f0 used. */
 int vsp_generator_halo_frames(const vsp_ctx* ctx);
+/* ABI 5: the SAMPLE-EXACT dependence of the vocoder's output frames on its input frames, from the configuration's kernel
+ * sizes, strides and dilations: output frame F depends on input frames [F - *back, F + *fwd] (13 / 13 for
+ * configs/config.json; the halo above is the coarser per-stage bound).  It is what the trimmed tails of a ragged batch
+ * rest on (VSP_TRIM_TAILS): an utterance of L frames is computed to L + back + 1 + fwd frames -- frames [0, L + back) as in
+ * the padded run, frame L + back the steady state of the zero input behind the utterance (periodic in one frame), the
+ * last fwd frames the tensor end's -- and the rest of the padded waveform is filled from those, bit for bit. */
+int vsp_generator_frame_dependence(const vsp_ctx* ctx, int* back, int* fwd);
 int64_t vsp_generator_stream_workspace_bytes(const vsp_ctx* ctx, int B, int chunk_frames);
 int vsp_generator_stream_chunk(vsp_ctx* ctx, void* stream, int B, int T, const float* z, const float* g, int f0, int f1,
                                float* o_chunk, void* workspace, int64_t workspace_bytes);

@@ -178,3 +178,16 @@ def test_typed_weights_and_begin_weights_host_logic(ctx):
     # an adopted arena cannot be committed without a device (and a context is not ready before)
     assert lib.vsp_commit_adopted_weights(h, None) == -2
     assert lib.vsp_generator_halo_frames(h) == 14
+    # ABI 5: the sample-exact frame dependence the trimmed tails rest on, against an independent derivation: an impulse at
+    # input position 0 reaches output samples [lo, hi]; conv (k, d): +- (k - 1) d / 2; transposed conv (k, s, p = (k - s) / 2):
+    # [lo, hi] -> [lo s - p, hi s - p + k - 1] (reference models.py:255-257, 271-290; modules.py:187-223)
+    back, fwd = C.c_int(-1), C.c_int(-1)
+    assert lib.vsp_generator_frame_dependence(h, C.byref(back), C.byref(fwd)) == 0
+    lo, hi, up = -3, 3, 1
+    for k, s in zip((16, 16, 4, 4), (8, 8, 4, 2)):
+        p = (k - s) // 2
+        lo, hi, up = lo * s - p, hi * s - p + k - 1, up * s
+        ext = max(sum((kk - 1) * d // 2 + (kk - 1) // 2 for d in (1, 3, 5)) for kk in (3, 7, 11))
+        lo, hi = lo - ext, hi + ext
+    lo, hi = lo - 3, hi + 3
+    assert up == 512 and (back.value, fwd.value) == (hi // up, (up - 1 - lo) // up) == (13, 13)

@@ -83,6 +83,7 @@ SIGNATURES = {
     "vsp_generator_workspace_bytes": (_I64, [_P, _I, _I]),
     "vsp_generator": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _I64]),
     "vsp_generator_halo_frames": (_I, [_P]),
+    "vsp_generator_frame_dependence": (_I, [_P, C.POINTER(_I), C.POINTER(_I)]),
     "vsp_generator_stream_workspace_bytes": (_I64, [_P, _I, _I]),
     "vsp_generator_stream_chunk": (_I, [_P, _P, _I, _I, _P, _P, _I, _I, _P, _P, _I64]),
     "vsp_flow_forward": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _I64]),

@@ -1522,6 +1522,12 @@ int vsp_generator_halo_frames(const vsp_ctx* ctx) {
   return (int)(w + 3);   // conv_pre k7
 }
 
+int vsp_generator_frame_dependence(const vsp_ctx* ctx, int* back, int* fwd) {
+  if (!ctx || !back || !fwd) return VSP_ERR_ARG;
+  generator_frame_dependence(ctx->cfg, ctx->model.g_pre.K > 0 ? ctx->model.g_pre.K : 7, ctx->model.post_k, *back, *fwd);
+  return VSP_OK;
+}
+
 int64_t vsp_generator_stream_workspace_bytes(const vsp_ctx* ctx, int B, int chunk_frames) {
   if (!ctx || B <= 0 || chunk_frames <= 0) return VSP_ERR_ARG;
   const int span = chunk_frames + 2 * vsp_generator_halo_frames(ctx);
