@@ -298,8 +298,10 @@ int vsp_set_noise_offset(vsp_ctx* ctx, int64_t first_element);
  * points; Slaney area normalisation): basis_host[n_mels][n_fft / 2 + 1], computed on the host in double precision.
  * librosa is a third-party dependency of the reference (requirements.txt, no version pinned) and is not vendored:
  * this restates its published algorithm.  fmax <= 0 means sampling_rate / 2.
- * PARITY UNPINNED: neither librosa nor torchaudio is in the build image, so the basis is checked only against the
- * oracle's independent restatement and one known answer from librosa's documentation (tests/test_mel.py). */
+ * Pinned (round 5) to a third party's implementation of the same routine: transformers.audio_utils.mel_filter_bank(norm =
+ * "slaney", mel_scale = "slaney") -- "adapted from torchaudio and librosa" -- agrees to fp32 rounding for the reference's
+ * configuration and three other shapes (tests/test_oracle_golden.py, on the CPU).  librosa itself and torchaudio are not
+ * in the build image: the reference's own call has never been run beside it. */
 int vsp_mel_filterbank(int sampling_rate, int n_fft, int n_mels, float fmin, float fmax, float* basis_host);
 /* spec_to_mel_torch (reference mel_processing.py:73-82): mel = log(clamp(basis @ spec, min = 1e-5)).
  * spec [B][n_fft / 2 + 1][T] and mel [B][n_mels][T] are device pointers; the basis is built and uploaded inside the

@@ -11,10 +11,11 @@ Pinning: the reference ships no tests or golden vectors for this path
 real reference (imported from /root/reference in the build container by
 ``tests/golden/make_golden.py``) on seeded synthetic weights and inputs;
 ``tests/test_oracle_golden.py`` checks this restatement against every stored
-stage boundary (infer: 4 cases, voice_conversion: 1, spline: 1).  ``spectrogram``
+stage boundary (infer: 5 cases, voice_conversion: 1, spline: 1).  ``spectrogram``
 is the exception: the reference's ``torch.stft`` call form is rejected by the
-installed torch, so that function is pinned against a float64 DFT, not against a
-reference run (parity unpinned in the task's sense).
+installed torch, so that function is pinned against ``torch.stft(..., return_complex=True)`` called
+argument for argument and a float64 DFT, not against a reference run; ``mel_filterbank`` (librosa absent) is pinned
+against transformers' implementation of librosa's routine.
 
 It is written independently of the reference's module classes: weight-norm is
 folded once, relative-position attention uses the closed banded form instead of
@@ -410,7 +411,9 @@ def mel_filterbank(sr: int, n_fft: int, n_mels: int, fmin: float = 0.0, fmax: Op
     its defaults (htk=False, norm='slaney'), which reference mel_processing.py:79 calls.  librosa is not in this
     image and the reference pins no version: this restates the published algorithm (linear below 1 kHz at
     200/3 Hz per mel, log above with step ln(6.4)/27; triangles between successive mel points; area
-    normalisation 2 / (f[m+2] - f[m])).  Parity unpinned; used only as an audio-domain metric in tests."""
+    normalisation 2 / (f[m+2] - f[m])).  Pinned (round 5) to transformers.audio_utils.mel_filter_bank(norm='slaney',
+    mel_scale='slaney') -- a third party's implementation adapted from librosa -- to fp32 rounding
+    (tests/test_oracle_golden.py); used only as an audio-domain metric in tests."""
     fmax = sr / 2.0 if fmax is None else fmax
     f_sp, min_log_hz = 200.0 / 3.0, 1000.0
     min_log_mel, logstep = min_log_hz / f_sp, np.log(6.4) / 27.0

@@ -1,8 +1,9 @@
 """Mel front end (reference mel_processing.py:73-112): the library's mel basis (host) and the GPU mel projection /
 mel spectrogram against the oracle's restatement.  librosa -- where the reference takes the basis from
 (mel_processing.py:79, 99; requirements.txt without a version) -- is not in this image: both sides restate its
-published Slaney algorithm, so this parity is UNPINNED by a reference run; the known-answer below is the one value
-librosa's own documentation prints for its default example."""
+published Slaney algorithm; the pin (round 5) is tests/test_oracle_golden.py: both agree to fp32 rounding with
+transformers.audio_utils.mel_filter_bank(norm="slaney", mel_scale="slaney"), a third party's implementation adapted from
+librosa.  The known-answer below is the one value librosa's own documentation prints for its default example."""
 import numpy as np
 import pytest
 import torch

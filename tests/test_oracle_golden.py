@@ -120,6 +120,30 @@ def test_oracle_mel_filterbank_properties():
     assert abs(int(m[0, :, 8].argmax()) - int(np.abs(fb[:, round(440.0 / df)]).argmax())) <= 1
 
 
+MEL_CASES = [(44100, 2048, 80, 0.0, None), (22050, 1024, 80, 0.0, 8000.0), (22050, 2048, 128, 0.0, None), (16000, 400, 80, 20.0, 7600.0)]
+
+
+@pytest.mark.parametrize("sr,n_fft,n_mels,fmin,fmax", MEL_CASES)
+def test_mel_basis_is_pinned_to_a_third_party_implementation_of_librosa_s_algorithm(sr, n_fft, n_mels, fmin, fmax):
+    """Round 5: the pin for the mel half (reference mel_processing.py:14, 78-79, 96-99:
+    `librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax)` with its defaults = Slaney scale + Slaney norm).  librosa and
+    torchaudio are not in the image, but `transformers` is: `transformers.audio_utils.mel_filter_bank(norm="slaney",
+    mel_scale="slaney")` -- "adapted from torchaudio and librosa ... librosa uses the 'slaney' implementation" (its
+    docstring), the basis behind HF's Whisper features -- is a third party's implementation of the same routine.  The
+    oracle's restatement AND the library's host function (`vsp_mel_filterbank`, no GPU involved) agree with it to fp32
+    rounding for the reference's configuration (44.1 kHz, n_fft 2048, 80 mels, 0 .. Nyquist: configs/config.json:27-33)
+    and three other shapes."""
+    from transformers.audio_utils import mel_filter_bank
+    from oracle.vispeech_oracle import mel_filterbank
+    from vispeech_amd.mel_processing import mel_filterbank as lib_filterbank
+    ref = mel_filter_bank(num_frequency_bins=n_fft // 2 + 1, num_mel_filters=n_mels, min_frequency=float(fmin),
+                          max_frequency=float(sr / 2 if fmax is None else fmax), sampling_rate=sr, norm="slaney",
+                          mel_scale="slaney").T
+    tol = 2e-7 * float(np.abs(ref).max()) + 1e-9
+    assert np.abs(np.asarray(mel_filterbank(sr, n_fft, n_mels, fmin, fmax), dtype=np.float64) - ref).max() <= tol
+    assert np.abs(np.asarray(lib_filterbank(sr, n_fft, n_mels, fmin, fmax), dtype=np.float64) - ref).max() <= tol
+
+
 def test_philox_restatement_known_answers():
     """The oracle's restatement of the library's noise stream (vsp_randn) is pinned on the Random123 known-answer
     vectors of Philox4x32-10 (kat_vectors: counter / key all zero, all ones)."""
@@ -141,7 +165,8 @@ def test_spectrogram_restatement_is_pinned_to_torch_stft():
     reference RUN can pin it; what can be pinned is the third-party routine it names: the oracle must equal
     (a) ``torch.stft(..., return_complex=True)`` post-processed exactly as the reference does on the real view
     (``.pow(2).sum(-1)``), argument for argument (mel_processing.py:63-66), and (b) an independent framing + numpy FFT of
-    the same definition (periodic Hann window, center=False, one-sided).  The mel BASIS stays unpinned (librosa absent)."""
+    the same definition (periodic Hann window, center=False, one-sided).  The mel BASIS: librosa is absent; its pin is the
+    transformers implementation of the same routine (test_mel_basis_is_pinned_to_a_third_party_implementation_... above)."""
     import torch.nn.functional as F
     from oracle.vispeech_oracle import spectrogram
     r = np.random.Generator(np.random.PCG64(5))

@@ -5,10 +5,11 @@ and ``win_size`` must be that model's ``filter_length`` (the reference always ca
 ``hps.data.filter_length`` / ``win_length`` of equal value, data_utils.py:60-64).  ``center`` must be False, as in
 every call of the reference.
 
-Parity status: the linear spectrogram is pinned to ``torch.stft`` (tests/test_mel.py); the MEL BASIS is **parity
-unpinned** -- librosa (the reference's source of it, mel_processing.py:14, 78, 96) and torchaudio are absent from the
-build image, so ``vsp_mel_filterbank`` is a restatement of librosa's published Slaney algorithm checked only against
-the oracle's independent restatement and one documented known answer."""
+Parity status: the linear spectrogram is pinned to ``torch.stft`` (tests/test_mel.py); the MEL BASIS -- librosa's
+``filters.mel`` in the reference (mel_processing.py:14, 78, 96) -- is pinned to a third party's implementation of that
+routine, ``transformers.audio_utils.mel_filter_bank(norm="slaney", mel_scale="slaney")`` ("adapted from torchaudio and
+librosa"), to fp32 rounding (tests/test_oracle_golden.py).  librosa and torchaudio themselves are absent from the build
+image: the reference's own call has not been run beside it."""
 from typing import Optional
 
 import torch
