@@ -126,6 +126,8 @@ def test_trimmed_tail_structure(net_untrimmed):
     {"VSP_TIMG": "0", "VSP_PP": "0"},            # fp32 intermediates, two-launch pairs at 128 channels
     {"VSP_CHAIN": "7"},                          # whole-ResBlock launches for k3, k7 and k11
     {"VSP_RW64": "1"},                           # the 64-channel k3 pairs on the register-weights kernel (opt-in)
+    {"VSP_RB_STREAMS": "15"},                    # the stages' ResBlock chains on side streams (opt-in; fork / join by events)
+    {"VSP_RB_STREAMS": "5", "VSP_FUSE_PAIRS": "0"},   # the same on stages 0 and 2 only, one launch per convolution
 ], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_trimmed_tails_under_every_kernel_selection(net_untrimmed, weights, monkeypatch, env):
     """Every generator kernel has the per-utterance extent: the second implementations, trimmed, equal the default

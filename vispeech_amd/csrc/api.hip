@@ -450,6 +450,27 @@ void run_generator(Run& r, int B, int T, T3 z, const int64_t* in_lengths, const 
 
 // Generator.forward on the split-f16 channels-last kernels (gen16.hip): conv_pre stays on the
 // f32 kernel (input z is channel-major and tiny), its output is transposed once to [B][T][C].
+// The context's two side streams and n fork / join events (created on first use, on the device the caller's stream
+// belongs to; destroyed with the context).
+bool ensure_side_streams(Run& r, size_t n_events) {
+  vsp_ctx* ctx = r.ctx;
+  // side[0]: the device's greatest stream priority, side[1]: its least (the caller's stream is assumed to sit between)
+  int least = 0, greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+  for (int k = 0; k < 2; ++k)
+    if (!ctx->side[k] &&
+        hipStreamCreateWithPriority(&ctx->side[k], hipStreamNonBlocking, k == 0 ? greatest : least) != hipSuccess) {
+      ctx->side[k] = nullptr;
+      return false;
+    }
+  while (ctx->sync_ev.size() < n_events) {
+    hipEvent_t e;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) return false;
+    ctx->sync_ev.push_back(e);
+  }
+  return true;
+}
+
 void run_generator_cl(Run& r, int B, int T, T3 z, const int64_t* in_lengths, const float* g, float* o) {
   const vsp_config& c = r.ctx->cfg;
   const Model& m = r.ctx->model;
@@ -467,6 +488,11 @@ void run_generator_cl(Run& r, int B, int T, T3 z, const int64_t* in_lengths, con
   }
   float* buf[5];
   for (auto& bptr : buf) bptr = r.ws.f((size_t)B * mx);
+  // ResBlocks 1 .. nk-1 of a stage on side streams (vsp_ctx::rb_streams): their own ping-pong tensors (and operand image)
+  std::vector<float*> side_buf;
+  if (r.ctx->rb_streams)
+    for (int j = 1; j < nk; ++j)
+      for (int u = 0; u < 2; ++u) side_buf.push_back(r.ws.f((size_t)B * mx));
   // the operand image of a ResBlock intermediate on the stages that run one launch per convolution (>= 128 channels)
   size_t mx_img = 0;
   {
@@ -477,7 +503,11 @@ void run_generator_cl(Run& r, int B, int T, T3 z, const int64_t* in_lengths, con
       if (chi >= 128 && chi % 32 == 0) mx_img = std::max(mx_img, cl_img_halfs(chi, (int)t) / 2);
     }
   }
-  uint16_t* timg = (r.ctx->t_img && mx_img && r.ctx->gen_mode == 1) ? reinterpret_cast<uint16_t*>(r.ws.f((size_t)B * mx_img)) : nullptr;
+  const bool want_img = r.ctx->t_img && mx_img && r.ctx->gen_mode == 1;
+  uint16_t* timg = want_img ? reinterpret_cast<uint16_t*>(r.ws.f((size_t)B * mx_img)) : nullptr;
+  std::vector<uint16_t*> side_img;
+  if (want_img && r.ctx->rb_streams)
+    for (int j = 1; j < nk; ++j) side_img.push_back(reinterpret_cast<uint16_t*>(r.ws.f((size_t)B * mx_img)));
   // Trimmed tails (round 5; VSP_TRIM_TAILS=0: off, second implementation, bit-identical).  Behind an utterance's last frame
   // the input is exactly zero (z * x_mask, reference models.py:720), so the output there depends on the distance to the
   // utterance's end and to the tensor's end only: every kernel below treats utterance b's tensor as ENDING after
@@ -536,15 +566,45 @@ void run_generator_cl(Run& r, int B, int T, T3 z, const int64_t* in_lengths, con
       r.glen = trim ? glen_all + b0 : nullptr;
       r.grate_in = (int)(Tn / T); r.grate_out = (int)(Tout / T);
       const float* xin = buf[cur] + (size_t)b0 * xbs;
-      float *xu = XU + (size_t)b0 * bs, *t1 = T1 + (size_t)b0 * bs, *ya = YA + (size_t)b0 * bs, *xs = XS + (size_t)b0 * bs;
+      float *xu = XU + (size_t)b0 * bs, *xs = XS + (size_t)b0 * bs;
       r.clconv(U, xin, xbs, xu, bs, nullptr, 0, (int)Tn, (int)Tn + 1, (int)Tout, 0.1f, false, 1.f, nb);
+      // The stage's ResBlocks are independent chains until their sum (reference models.py:276-285): chain 0 runs on the
+      // caller's stream, chains 1 .. on the context's side streams with their own intermediates, forked after the
+      // up-convolution; a chain's LAST launch accumulates into xs and therefore waits for the previous chain's last
+      // launch (the reference's order of the sum, bit for bit), the caller's stream joins after the last chain.
+      const bool conc = ((r.ctx->rb_streams >> i) & 1) && !r.ctx->prof_on && !r.dry() && r.ok() && Bc == B && nk > 1 &&
+                        (int)side_buf.size() == 2 * (nk - 1) && ensure_side_streams(r, (size_t)c.n_upsamples * (nk + 1));
+      hipStream_t const main_s = r.s;
+      hipEvent_t* const ev = conc ? r.ctx->sync_ev.data() + (size_t)i * (nk + 1) : nullptr;   // [0] fork, [1 + j] chain j's last launch
       // stages that run one launch per convolution hand the pair's intermediate over as an operand image
-      uint16_t* ti = (timg && ch >= 128 && ch % 32 == 0) ? timg + (size_t)b0 * cl_img_halfs(ch, (int)Tout) : nullptr;
-      if (ti && !r.dry() && r.ok())
-        r.chk(launch_cl_img_zero_pads(ti, nb, ch, (int)Tout, r.s, r.glen, r.grate_out), "cl_img_zero_pads");
+      const bool use_img = timg && ch >= 128 && ch % 32 == 0;
+      auto chain_img = [&](int j) -> uint16_t* {
+        if (!use_img) return nullptr;
+        uint16_t* base = (conc && j != 1 && (int)side_img.size() == nk - 1) ? side_img[j == 0 ? 0 : j - 1] : timg;
+        return base + (size_t)b0 * cl_img_halfs(ch, (int)Tout);
+      };
+      if (use_img && !r.dry() && r.ok())
+        for (int j = (conc && !side_img.empty()) ? 0 : 1; j < ((conc && !side_img.empty()) ? nk : 2); ++j)
+          r.chk(launch_cl_img_zero_pads(chain_img(j), nb, ch, (int)Tout, r.s, r.glen, r.grate_out), "cl_img_zero_pads");
+      if (conc) r.chk(hipEventRecord(ev[0], main_s), "fork event");
       for (int j = 0; j < nk; ++j) {
         const ResBlockW& rb = m.rbs[i * nk + j];
         const int nd = (int)rb.dil.size();
+        // chain j's stream and intermediates: chain 0 on the high-priority side stream, chain 1 on the caller's, the rest
+        // on the low-priority one -- the hardware then dispatches a chain's blocks into the slots the chains before it
+        // leave free (ramps, partial last rounds) instead of sharing the CUs launch by launch in lockstep, and a chain's
+        // last launch finds the previous chain's long finished
+        float *t1 = T1 + (size_t)b0 * bs, *ya = YA + (size_t)b0 * bs;
+        const int side_set = j == 0 ? 0 : j - 1;           // (chain 1 keeps the caller-stream tensors)
+        if (conc && j != 1) {
+          r.s = r.ctx->side[j == 0 ? 0 : 1];
+          t1 = side_buf[2 * side_set] + (size_t)b0 * bs;
+          ya = side_buf[2 * side_set + 1] + (size_t)b0 * bs;
+          r.chk(hipStreamWaitEvent(r.s, ev[0], 0), "fork wait");
+        }
+        uint16_t* const ti = chain_img(j);
+        auto before_last = [&]() { if (conc && j > 0) r.chk(hipStreamWaitEvent(r.s, ev[j], 0), "sum order wait"); };
+        auto after_last = [&]() { if (conc) r.chk(hipEventRecord(ev[1 + j], r.s), "chain end event"); r.s = main_s; };
         bool fuse = r.ctx->fuse_pairs;
         const int terms = r.ctx->gen_mode == 2 ? 1 : 3;
         for (int d = 0; d < nd; ++d)
@@ -552,7 +612,9 @@ void run_generator_cl(Run& r, int B, int T, T3 z, const int64_t* in_lengths, con
         const int kbit = rb.k <= 3 ? 1 : rb.k <= 7 ? 2 : 4;
         if (fuse && (r.ctx->chain_mask & kbit) && ch <= r.ctx->chain_ch && nd <= 3 &&
             g16_chain_supported(ch, rb.k, rb.dil.data(), nd)) {
+          before_last();
           r.clchain(rb, ch, xu, xs, bs, (int)Tout, j > 0, j == nk - 1 ? (float)nk : 1.f, nb);
+          after_last();
           continue;
         }
         for (int d = 0; d < nd; ++d) {
@@ -563,22 +625,28 @@ void run_generator_cl(Run& r, int B, int T, T3 z, const int64_t* in_lengths, con
             // that a neighbour writes, so a pair cannot run in place)
             const float* yin = d == 0 ? xu : ((d & 1) ? ya : t1);
             float* yout = last ? xs : ((d & 1) ? t1 : ya);
+            if (last) before_last();
             r.clpair(rb.h1[d], rb.h2[d], yin, yout, bs, (int)Tout, last && j > 0, div, nb);
           } else if (ch == 128 && (r.ctx->chain128_mask & kbit) && g16_chain_supported(ch, rb.k, &rb.dil[d], 1)) {
             // 128-channel pair as ONE launch (g16_chain, 128-column blocks): the intermediate never reaches HBM
             const float* yin = d == 0 ? xu : ((d & 1) ? ya : t1);
             float* yout = last ? xs : ((d & 1) ? t1 : ya);
+            if (last) before_last();
             r.clchain(rb, ch, yin, yout, bs, (int)Tout, last && j > 0, div, nb, d, 1);
           } else {
             const float* yin = d == 0 ? xu : ya;
             const bool img = ti != nullptr && rb.k >= 3;
             r.clconv(rb.h1[d], yin, bs, img ? nullptr : t1, bs, nullptr, 0, (int)Tout, (int)Tout, (int)Tout, 0.1f, false, 1.f,
                      nb, nullptr, img ? ti : nullptr);
+            if (last) before_last();
             r.clconv(rb.h2[d], t1, bs, last ? xs : ya, bs, yin, bs, (int)Tout, (int)Tout, (int)Tout, 0.1f,
                      last && j > 0, div, nb, img ? ti : nullptr, nullptr);
           }
         }
+        after_last();
       }
+      r.s = main_s;
+      if (conc) r.chk(hipStreamWaitEvent(main_s, ev[nk], 0), "join wait");
     }
     cur = fb[3];
     Tn = Tout;
@@ -666,6 +734,7 @@ int vsp_create(const vsp_config* cfg, int device, vsp_ctx** out) {
   if (const char* e = getenv("VSP_CHAIN")) ctx->chain_mask = atoi(e);
   if (const char* e = getenv("VSP_RW64")) ctx->rw64 = atoi(e) != 0;               // 1: g16_rw64 for the 64-channel k3 pairs (opt-in)
   if (const char* e = getenv("VSP_TRIM_TAILS")) ctx->trim_tails = atoi(e) != 0;   // 0: every utterance runs to the padded length
+  if (const char* e = getenv("VSP_RB_STREAMS")) ctx->rb_streams = atoi(e);   // stage mask: ResBlock chains on side streams (opt-in, measured slower)
 #ifdef VSP_EXPERIMENTS
   if (const char* e = getenv("VSP_ATT_KSPLIT")) ctx->att_ksplit = atoi(e);
   if (const char* e = getenv("VSP_CHUNK_MB")) ctx->chunk_mb = atof(e);
@@ -682,6 +751,8 @@ int vsp_create(const vsp_config* cfg, int device, vsp_ctx** out) {
 int vsp_destroy(vsp_ctx* ctx) {
   if (!ctx) return VSP_ERR_ARG;
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
+  for (auto e : ctx->sync_ev) (void)hipEventDestroy(e);
+  for (auto st : ctx->side) if (st) (void)hipStreamDestroy(st);
   if (ctx->arena && ctx->arena_owned) (void)hipFree(ctx->arena);
   delete ctx;
   return VSP_OK;

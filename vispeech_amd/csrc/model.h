@@ -120,6 +120,14 @@ struct vsp_ctx {
   bool rw64 = false;              // VSP_RW64=1: the 64-channel k3 pairs on g16_rw64 (register weights; measured slower: opt-in)
   bool trim_tails = true;         // ragged batches: the generator runs each utterance to length + 2 halo + 1 frames and fills the
                                   // padded tail from the steady state (VSP_TRIM_TAILS=0: to the padded length; bit-identical)
+  // round 5, measured and NOT adopted (profiles/r05_resblock_chains_on_side_streams.txt): the ResBlocks of a generator stage
+  // (independent until their sum, reference models.py:276-285) on the caller's stream and two side streams of the context,
+  // forked / joined by events, so that the ramp and the partial last round of one launch are covered by another chain's
+  // blocks.  VSP_RB_STREAMS=<stage mask> (bit i = stage i; 0 = one stream, the product); bit-identical either way; profiled
+  // steps always run on one stream so that the per-launch events time one kernel each.
+  int rb_streams = 0;
+  hipStream_t side[2] = {nullptr, nullptr};
+  std::vector<hipEvent_t> sync_ev;
   int64_t noise_first = 0;        // stream index of element 0 of a library-drawn noise tensor (vsp_set_noise_offset)
   bool adopted_pending = false;   // an adopted arena whose header has not been checked yet (vsp_commit_adopted_weights)
   int gen_mode = 1;  // 0: f32 MFMA channel-major generator, 1: split-f16 (fp32-accurate) channels-last generator,
