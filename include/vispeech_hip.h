@@ -142,7 +142,12 @@ int vsp_encode(vsp_ctx* ctx, void* stream, int B, int Tp,
                float* x_var, float* g, float* duration, float* f0, float* energy,
                int64_t* frame_lengths, int32_t* cum_dur,
                void* workspace, int64_t workspace_bytes);
-/* Copies frame_lengths[B] to the host (one stream sync) and returns max(frame_lengths). */
+/* Copies frame_lengths[B] to the host and returns max(frame_lengths): the one host wait of an infer call.  After a
+ * vsp_encode with duration_ctl != NULL (given durations: the counts depend on nothing vsp_encode computes) it waits only
+ * for the copy vsp_encode started before its first launch -- the text encoder may still be running on the stream when it
+ * returns, and vsp_decode enqueued behind it finds no idle GPU between the two halves; otherwise (predicted durations,
+ * or a frame_lengths_dev that is not the last vsp_encode's) it is a copy + one stream synchronisation.  The pinned
+ * B x int64 host buffer and the event behind this are created by the first such vsp_encode and kept with the context. */
 int vsp_frame_lengths_host(vsp_ctx* ctx, void* stream, int B, const int64_t* frame_lengths_dev,
                            int64_t* frame_lengths_host, int64_t* max_frames);
 

@@ -734,6 +734,7 @@ int vsp_create(const vsp_config* cfg, int device, vsp_ctx** out) {
   if (const char* e = getenv("VSP_CHAIN")) ctx->chain_mask = atoi(e);
   if (const char* e = getenv("VSP_RW64")) ctx->rw64 = atoi(e) != 0;               // 1: g16_rw64 for the 64-channel k3 pairs (opt-in)
   if (const char* e = getenv("VSP_TRIM_TAILS")) ctx->trim_tails = atoi(e) != 0;   // 0: every utterance runs to the padded length
+  if (const char* e = getenv("VSP_EARLY_FL")) ctx->early_fl = atoi(e) != 0;
   if (const char* e = getenv("VSP_RB_STREAMS")) ctx->rb_streams = atoi(e);   // stage mask: ResBlock chains on side streams (opt-in, measured slower)
 #ifdef VSP_EXPERIMENTS
   if (const char* e = getenv("VSP_ATT_KSPLIT")) ctx->att_ksplit = atoi(e);
@@ -752,6 +753,8 @@ int vsp_destroy(vsp_ctx* ctx) {
   if (!ctx) return VSP_ERR_ARG;
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
   for (auto e : ctx->sync_ev) (void)hipEventDestroy(e);
+  if (ctx->fl_ev) (void)hipEventDestroy(ctx->fl_ev);
+  if (ctx->fl_pinned) (void)hipHostFree(ctx->fl_pinned);
   for (auto st : ctx->side) if (st) (void)hipStreamDestroy(st);
   if (ctx->arena && ctx->arena_owned) (void)hipFree(ctx->arena);
   delete ctx;
@@ -971,6 +974,27 @@ int vsp_weight_arena(const vsp_ctx* ctx, void** dev_arena, int64_t* bytes) {
 }
 
 // -------------------------------------------------------------------------------------------- encode
+// pinned host buffer + event of the early frame-count copy (created on first use, grown by doubling; kept with the context)
+static bool early_frame_lengths_ready(vsp_ctx* ctx, int B) {
+  if (!ctx->fl_ev && hipEventCreateWithFlags(&ctx->fl_ev, hipEventDisableTiming) != hipSuccess) {
+    ctx->fl_ev = nullptr;
+    return false;
+  }
+  if (ctx->fl_cap < B) {
+    if (ctx->fl_pinned) (void)hipHostFree(ctx->fl_pinned);
+    ctx->fl_pinned = nullptr;
+    int cap = std::max(64, ctx->fl_cap);
+    while (cap < B) cap *= 2;
+    if (hipHostMalloc(reinterpret_cast<void**>(&ctx->fl_pinned), (size_t)cap * sizeof(int64_t), hipHostMallocDefault) != hipSuccess) {
+      ctx->fl_pinned = nullptr;
+      ctx->fl_cap = 0;
+      return false;
+    }
+    ctx->fl_cap = cap;
+  }
+  return true;
+}
+
 static int encode_impl(vsp_ctx* ctx, hipStream_t s, Ws& ws, int B, int Tp, const int64_t* phonemes,
                        const int64_t* lengths, const int64_t* sid, const float* dctl, const float* pctl,
                        const float* ectl, float dscale, float pscale, float escale, float* x_var, float* g,
@@ -994,12 +1018,22 @@ static int encode_impl(vsp_ctx* ctx, hipStream_t s, Ws& ws, int B, int Tp, const
     r.chk(launch_embed(phonemes, r.A(m.emb_sym), c.n_vocab, sqrtf((float)h), XE.p, XE.bs, XE.cs, B, h, Tp, s),
           "symbol_emb");
   }
+  // ---- given durations (models.py:681): the frame counts need nothing computed here -- derive them FIRST and start their
+  // copy to the host, so that vsp_frame_lengths_host returns while the text encoder runs (vsp_ctx::fl_pinned)
+  if (live) ctx->fl_src = nullptr;
+  if (dctl && live) {
+    r.chk(hipMemcpyAsync(duration, dctl, (size_t)B * Tp * sizeof(float), hipMemcpyDeviceToDevice, s), "dur copy");
+    r.chk(launch_duration_cumsum(duration, cum_dur, frame_lengths, B, Tp, s), "duration cumsum");
+    if (r.ok() && ctx->early_fl && early_frame_lengths_ready(ctx, B)) {
+      hipError_t e = hipMemcpyAsync(ctx->fl_pinned, frame_lengths, (size_t)B * sizeof(int64_t), hipMemcpyDeviceToHost, s);
+      if (e == hipSuccess) e = hipEventRecord(ctx->fl_ev, s);
+      if (e == hipSuccess) { ctx->fl_src = frame_lengths; ctx->fl_n = B; }
+    }
+  }
   mask3(r, XE, lengths, B, h, Tp);  // TextEncoder passes x * x_mask (models.py:173)
   run_encoder_masked(r, m.enc[0], B, Tp, XE, lengths, XV);   // XV = x_enc
   // ---- duration (models.py:681-688, 119-133)
-  if (dctl) {
-    if (live) r.chk(hipMemcpyAsync(duration, dctl, (size_t)B * Tp * sizeof(float), hipMemcpyDeviceToDevice, s), "dur copy");
-  } else {
+  if (!dctl) {
     const int f = c.dur_filter;
     T3 A1 = P1, A2 = P2;
     r.cond(m.dur_cond, g, cvec, B);
@@ -1049,7 +1083,7 @@ static int encode_impl(vsp_ctx* ctx, hipStream_t s, Ws& ws, int B, int Tp, const
   if (live) {
     r.chk(launch_energy(ectl, pred, escale, norm_e, energy, B * Tp, s), "energy");
     r.chk(launch_prenet_add(XV.p, XV.bs, XV.cs, r.A(m.epre_w), r.A(m.epre_b), norm_e, B, h, Tp, s), "energy_prenet");
-    r.chk(launch_duration_cumsum(duration, cum_dur, frame_lengths, B, Tp, s), "duration cumsum");
+    if (!dctl) r.chk(launch_duration_cumsum(duration, cum_dur, frame_lengths, B, Tp, s), "duration cumsum");
   }
   if (ws.overflow) return ctx->fail(VSP_ERR_WORKSPACE, "encode workspace too small (need %zu bytes)", ws.cur);
   return r.rc;
@@ -1085,9 +1119,17 @@ int vsp_frame_lengths_host(vsp_ctx* ctx, void* stream, int B, const int64_t* fra
                            int64_t* frame_lengths_host, int64_t* max_frames) {
   if (!ctx || B <= 0 || !frame_lengths_dev || !frame_lengths_host || !max_frames)
     return ctx ? ctx->fail(VSP_ERR_ARG, "vsp_frame_lengths_host: bad argument") : VSP_ERR_ARG;
-  hipError_t e = hipMemcpyAsync(frame_lengths_host, frame_lengths_dev, (size_t)B * sizeof(int64_t),
-                                hipMemcpyDeviceToHost, (hipStream_t)stream);
-  if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+  hipError_t e;
+  if (ctx->fl_src == frame_lengths_dev && ctx->fl_n == B) {
+    // vsp_encode already started this copy (given durations): wait for IT, not for the rest of the stream
+    e = hipEventSynchronize(ctx->fl_ev);
+    if (e == hipSuccess) std::memcpy(frame_lengths_host, ctx->fl_pinned, (size_t)B * sizeof(int64_t));
+    ctx->fl_src = nullptr;
+  } else {
+    e = hipMemcpyAsync(frame_lengths_host, frame_lengths_dev, (size_t)B * sizeof(int64_t), hipMemcpyDeviceToHost,
+                       (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+  }
   if (e != hipSuccess) return ctx->fail(VSP_ERR_HIP, "frame length read: %s", hipGetErrorString(e));
   int64_t mx = 0;
   for (int b = 0; b < B; ++b) mx = std::max(mx, frame_lengths_host[b]);

@@ -126,6 +126,14 @@ struct vsp_ctx {
   // blocks.  VSP_RB_STREAMS=<stage mask> (bit i = stage i; 0 = one stream, the product); bit-identical either way; profiled
   // steps always run on one stream so that the per-launch events time one kernel each.
   int rb_streams = 0;
+  // the frame counts of a batch whose durations are GIVEN (duration_control tensor) depend on nothing vsp_encode computes:
+  // it derives them first, copies them to this pinned buffer and records fl_ev, so that vsp_frame_lengths_host waits for
+  // that copy only while the text encoder still runs (no idle GPU between the two halves of an infer call)
+  bool early_fl = true;              // VSP_EARLY_FL=0: vsp_frame_lengths_host always synchronises the stream
+  int64_t* fl_pinned = nullptr;
+  int fl_cap = 0, fl_n = 0;
+  hipEvent_t fl_ev = nullptr;
+  const int64_t* fl_src = nullptr;   // device tensor the pending early copy was taken from (nullptr: none pending)
   hipStream_t side[2] = {nullptr, nullptr};
   std::vector<hipEvent_t> sync_ev;
   int64_t noise_first = 0;        // stream index of element 0 of a library-drawn noise tensor (vsp_set_noise_offset)
