@@ -64,9 +64,9 @@ def test_cl_conv1d_matches_torch(lib, cin, cout, k, dil, b, t):
 
 
 def test_cl_conv1d_small_amplitude_activations_stay_within_the_documented_bound(lib):
-    """the operand split keeps hi + lo = 21 bits of an operand over the f16 NORMAL range; activations below
-    2^-14 land in f16 subnormals and lose up to 2^-24 ABSOLUTE each (g16_common.h).  With every activation at ~1e-5 the
-    result is held to that bound: |err| <= 2^-24 sum|w| + 1e-5 max|ref|."""
+    """The operand split keeps hi + lo = 21 bits of an activation where |x| >= 2^-4 and x to within 2^-24 ABSOLUTE below
+    (the lo part is then an f16 subnormal; g16_common.h).  With every activation at ~1e-5 the result is held to that
+    bound: |err| <= 2^-24 sum|w| + 1e-5 max|ref|."""
     cin, cout, k, t = 64, 64, 7, 300
     r = np.random.Generator(np.random.PCG64(3))
     x = (r.standard_normal((1, t, cin)) * 1e-5).astype(np.float32)
@@ -80,6 +80,25 @@ def test_cl_conv1d_small_amplitude_activations_stay_within_the_documented_bound(
     ref = F.conv1d(torch.from_numpy(x).double().transpose(1, 2), torch.from_numpy(w).double(), padding=3).transpose(1, 2).numpy()
     bound = 2.0 ** -24 * float(np.abs(w).sum(axis=(1, 2)).max()) + 1e-5 * float(np.abs(ref).max())
     assert float(np.abs(out.cpu().numpy() - ref).max()) <= bound
+
+
+def test_cl_conv1d_small_weights_keep_fp32_accuracy(lib):
+    """The weights are packed * 2^8 (kernels.h G16_WSCALE, exact) so that their lo parts stay NORMAL f16 numbers whatever the
+    trained magnitude: with weights of ~1e-3 (lo parts of 5e-7, under the smallest f16 subnormal step times 8 when
+    unscaled) the result still matches fp64 to 1e-6 of its maximum -- unscaled lo parts would be off by ~2e-5."""
+    cin, cout, k, t = 64, 64, 7, 300
+    r = np.random.Generator(np.random.PCG64(4))
+    x = r.standard_normal((1, t, cin)).astype(np.float32)
+    w = (r.standard_normal((cout, cin, k)) * 1e-3).astype(np.float32)
+    bias = (r.standard_normal(cout) * 1e-2).astype(np.float32)
+    out = torch.empty(1, t, cout, device="cuda")
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = lib.vsp_cl_conv1d(stream, 1, t, cin, cout, k, 1, P(torch.from_numpy(x).cuda()), w.ctypes.data_as(C.c_void_p),
+                           bias.ctypes.data_as(C.c_void_p), 1.0, None, 3, P(out))
+    assert rc == 0
+    ref = F.conv1d(torch.from_numpy(x).double().transpose(1, 2), torch.from_numpy(w).double(),
+                   torch.from_numpy(bias).double(), padding=3).transpose(1, 2).numpy()
+    assert float(np.abs(out.cpu().numpy() - ref).max()) <= 1e-6 * float(np.abs(ref).max())
 
 
 def torch_resblock(x, ws, bs, dils, k):

@@ -1767,9 +1767,9 @@ hipError_t upload_cl_conv(const float* w_host, const float* bias_host, int Cout,
   hipError_t e = w.alloc(packed.size() * 2);
   if (e == hipSuccess) e = bias.alloc((size_t)Cout * 4);
   if (e == hipSuccess) e = hipMemcpyAsync(w.p, packed.data(), packed.size() * 2, hipMemcpyHostToDevice, s);
-  std::vector<float> zero;
-  if (!bias_host) { zero.assign(Cout, 0.f); bias_host = zero.data(); }
-  if (e == hipSuccess) e = hipMemcpyAsync(bias.p, bias_host, (size_t)Cout * 4, hipMemcpyHostToDevice, s);
+  std::vector<float> scaled(Cout, 0.f);                  // (kernels.h: these kernels take the bias * G16_WSCALE)
+  if (bias_host) for (int i = 0; i < Cout; ++i) scaled[i] = bias_host[i] * G16_WSCALE;
+  if (e == hipSuccess) e = hipMemcpyAsync(bias.p, scaled.data(), (size_t)Cout * 4, hipMemcpyHostToDevice, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);     // the host vectors die with this frame
   return e;
 }

@@ -104,39 +104,47 @@ __device__ __forceinline__ void g16_for(F&& f) {
 }
 
 // leaky-relu + split of four fp32 values -> hi / lo f16x4.
-// Round 3: built from the fewest vector instructions that keep the split exact (18 per four values instead of 32):
+// Built from the fewest vector instructions that keep the split exact (round 3: 18 per four values instead of 32; round 5:
+// 14, the lo parts are no longer scaled -- "ONE accumulator per tile" below):
 //   hi = x with the mantissa TRUNCATED to f16 precision: one v_and_b32 on the fp32 bits (0xffffe000); exactly
 //        representable in f16 over the normal range, so v_cvt_pkrtz_f16_f32 packs two of them in ONE instruction
 //        without rounding (and saturates at the largest finite f16 instead of producing inf);
-//   lo = (x - hi) * 2^11: the residual is exact in fp32 (no conversion back from f16); packed by v_cvt_pkrtz as well.
-// Truncation instead of round-to-nearest leaves |x - hi| <= 2^-10 |x| (one bit more than before): hi + lo keeps 21
-// bits of x instead of 22 -- 2^-21 relative per operand, below the fp32 accumulation noise of a 96 .. 2816-term dot
-// product (measured waveform error unchanged, 1e-6).  Every generator kernel splits with this one function, so the
-// ResBlock implementations stay bit-identical.
-// Caveat: "exactly representable" holds over the f16 NORMAL range.  Below it (|x| < 2^-14 = 6.1e-5) the
-// packed hi is a subnormal f16 that keeps fewer than 11 bits while lo is still taken against the fp32-truncated value,
-// so hi + lo loses up to 2^-24 ABSOLUTE per operand there -- below the fp32 accumulation noise of any activation that
-// matters (vocoder activations are O(1e-2 .. 1)); tests/test_cl_ops.py keeps a small-amplitude case.
-// G16_SPLIT_PLAIN (late round 4): the subtraction, the two scalings as PLAIN f32 instructions (asm, so that hipcc does not
+//   lo = x - hi: exact in fp32 (no conversion back from f16); packed by v_cvt_pkrtz as well.  |lo| <= 2^-10 |x|: a normal
+//        f16 number while |x| >= 2^-4, an f16 SUBNORMAL below (the packing then truncates it to a multiple of 2^-24).
+// So hi + lo keeps 21 bits of x where |x| >= 2^-4 and x to within 2^-24 ABSOLUTE below -- activations of 1e-2 .. 1e-1
+// keep 17-20 bits.  In a dot product that is |error| <= 2^-24 sum|w| per output, the same bound the round-3 form had for
+// |x| < 2^-14 only, and below the fp32 accumulation noise of a 96 .. 2816-term sum against outputs of O(1e-2 .. 1)
+// (measured: waveform error against the fp64 oracle 1.5e-6 before, 1.9e-6 now; tests/test_cl_ops.py holds the bound with
+// every activation at 1e-5 and a relative 1e-6 with weights of 1e-3).  Every generator kernel splits with this one
+// function, so the ResBlock implementations stay bit-identical.
+// G16_SPLIT_PLAIN (late round 4): the subtraction and the leaky-relu scaling as PLAIN f32 instructions (asm, so that hipcc does not
 // SLP-pack them): beside an MFMA stream a v_pk_*_f32 costs far more issue time than the two plain instructions it
 // replaces (MI355X_MICROARCH.md, constants table: "an anti-lever beside MFMAs"), and these kernels' vector work runs
 // beside MFMAs.  Same arithmetic, same bits.  CAUTION: hipcc's hazard recognizer does not see into inline asm -- an asm
-// instruction that reads an MFMA RESULT register directly gets no wait states and reads a stale value (tried: hh + cr /
-// 2048 as asm v_fma_f32: errors of 1e-4).  Every caller hands g16_split4 values that a compiler-generated vector
+// instruction that reads an MFMA RESULT register directly gets no wait states and reads a stale value (tried in round 4
+// on the fold of the then two accumulators as asm v_fma_f32: errors of 1e-4).  Every caller hands g16_split4 values that a compiler-generated vector
 // instruction has produced (the fold, a select).
 #ifndef G16_SPLIT_PLAIN
 #define G16_SPLIT_PLAIN 1
 #endif
+// ONE accumulator per tile (round 5).  Rounds 2-4 carried the lo parts * 2^11 (normal f16 numbers at any magnitude) and gave
+// the two cross products an accumulator of their own (cr), folded at the end as hh + cr / 2048.  The matrix core keeps f16
+// DENORMAL inputs (tools/micro/mfma_f16_denorm.hip: exact products of 2^-24), so the lo parts can stay UNSCALED -- lo = x - hi,
+// exact to 2^-25 absolute where it falls under 2^-14 -- and HH, CROSS, CROSS accumulate into one fp32 register set: half the
+// accumulator registers, no fold, one vector instruction less per split value.  The WEIGHTS are packed * G16_WSCALE (a power
+// of two: exact) so that their lo parts stay normal numbers for any trained magnitude (|w| of 1e-2 has lo parts of 5e-6);
+// the bias rides in the accumulator * G16_WSCALE as well (weights.cpp, upload_cl_conv) and every result leaves the
+// accumulator through * G16_UNSCALE -- exact, and x * G16_UNSCALE + residual contracts to one fma with the same bits.
+// Measured: step 71.4 -> 68.9 ms same box with every parity test green (profiles/r05_one_accumulator.txt).
+// (G16_WSCALE / G16_UNSCALE: kernels.h)
 __device__ __forceinline__ void g16_split2(f32x2 x, f16x2& h, f16x2& l) {
   const f32x2 hf = {__uint_as_float(__float_as_uint(x.x) & 0xffffe000u), __uint_as_float(__float_as_uint(x.y) & 0xffffe000u)};
 #if G16_SPLIT_PLAIN
   f32x2 lf;
   asm("v_sub_f32 %0, %1, %2" : "=v"(lf.x) : "v"(x.x), "v"(hf.x));
   asm("v_sub_f32 %0, %1, %2" : "=v"(lf.y) : "v"(x.y), "v"(hf.y));
-  asm("v_mul_f32 %0, 0x45000000, %1" : "=v"(lf.x) : "v"(lf.x));          // * 2048
-  asm("v_mul_f32 %0, 0x45000000, %1" : "=v"(lf.y) : "v"(lf.y));
 #else
-  const f32x2 lf = (x - hf) * 2048.f;
+  const f32x2 lf = x - hf;
 #endif
   h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(hf.x, hf.y));
   l = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(lf.x, lf.y));

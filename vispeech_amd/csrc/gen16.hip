@@ -1,10 +1,11 @@
 // Vocoder convolutions on the f16 matrix core with SPLIT operands -- fp32-accurate at ~4.6x the native f32 MFMA rate
 // (measured on MI355X, profiles/r01_exp_split_f16.log: error of the 3-term split 6e-8 * sum|ab|, no worse than an f32
 // fmaf chain):
-//   x = xh + xl * 2^-11,  xh = f16(x),  xl = f16((x - xh) * 2^11)      (exact residual, scaled so that the
-//   w = wh + wl * 2^-11                                                  low part never underflows)
-//   x*w ~= xh*wh + (xh*wl + xl*wh) * 2^-11        (dropped xl*wl term <= 2^-24 |x w|)
-//   -> two f32 accumulators per output tile: HH and CROSS; result = HH + CROSS * 2^-11.
+//   x = xh + xl,  xh = x truncated to f16 precision,  xl = f16(x - xh)   (exact residual; an f16 subnormal where |x| < 2^-4:
+//   w = wh + wl   (packed * 2^8: wl stays a normal number)                 the matrix core keeps those, g16_common.h)
+//   x*w ~= xh*wh + xh*wl + xl*wh                  (dropped xl*wl term <= 2^-22 |x w|)
+//   -> ONE f32 accumulator per output tile (round 5; rounds 2-4 carried the lo parts * 2^11 and gave the cross products an
+//      accumulator of their own): three MFMAs per 32-deep step into the same registers, result = accumulator * 2^-8.
 //
 // Why a second generation of these kernels (round 2):
 //   * MFMA shape.  Under the chip's power cap the 16x16x32 form sustains 1.15x the FLOP/s of 32x32x16 on
@@ -53,9 +54,9 @@ void pack_g16_weights(uint16_t* dst, int rows, int Cin, int K, const float* dens
   for (int r = 0; r < rows; ++r)
     for (int ci = 0; ci < Cin; ++ci)
       for (int tap = 0; tap < K; ++tap) {
-        const float w = dense[((size_t)r * Cin + ci) * K + tap];
+        const float w = dense[((size_t)r * Cin + ci) * K + tap] * G16_WSCALE;   // (g16_common.h: exact, keeps lo normal)
         const _Float16 h = (_Float16)w;
-        const _Float16 l = (_Float16)((w - (float)h) * 2048.f);
+        const _Float16 l = (_Float16)(w - (float)h);
         const int chunk = ci / 32, kk = ci % 32, mt = r / 16, lane = (r % 16) + 16 * (kk / 8), j = kk % 8;
         const size_t blk = (((size_t)chunk * K + tap) * nmt + mt) * 2;
         std::memcpy(dst + (blk * 64 + lane) * 8 + j, &h, 2);
@@ -222,7 +223,7 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
   f16x8 Ah[MW], Al[MW], Bh[NW], Bl[NW];
 
   // accumulators start at the bias: a lane holds rows 4 (l >> 4) .. + 3 of its m-tiles
-  f32x4 hh[MW][NW], cr[MW][NW];
+  f32x4 hh[MW][NW];
 #pragma unroll
   for (int i = 0; i < MW; ++i) {
     const int row = ((cb * MTB + wm * MW + i) << 4) + 4 * (lane >> 4);
@@ -230,7 +231,7 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + co);
 #pragma unroll
-    for (int j = 0; j < NW; ++j) { hh[i][j] = bv; cr[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int j = 0; j < NW; ++j) hh[i][j] = bv;
   }
 
   // ---- prologue: window chunk 0, slices 0 .. 2
@@ -318,8 +319,8 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
         constexpr int i = decltype(I)::value;
         hh[i][j] = G16_MFMA(Ah[i], Bh[j], hh[i][j]);
         if constexpr (TERMS == 3) {
-          cr[i][j] = G16_MFMA(Al[i], Bh[j], cr[i][j]);
-          cr[i][j] = G16_MFMA(Ah[i], Bl[j], cr[i][j]);
+          hh[i][j] = G16_MFMA(Al[i], Bh[j], hh[i][j]);
+          hh[i][j] = G16_MFMA(Ah[i], Bl[j], hh[i][j]);
         }
       });
     });
@@ -350,7 +351,7 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
     for (int i = 0; i < MW; ++i)
 #pragma unroll
       for (int j = 0; j < NW; ++j) {
-        f32x4 v = hh[i][j] + cr[i][j] * (1.f / 2048.f);
+        f32x4 v = hh[i][j] * G16_UNSCALE;
         g16_div(v, a.div);
         f16x4 eh, el;
         g16_split4(v, a.oi_slope, true, eh, el);
@@ -392,8 +393,7 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
     for (int i = 0; i < MW; ++i)
 #pragma unroll
       for (int j = 0; j < NW; ++j) {
-        f32x4 v = hh[i][j];
-        if constexpr (TERMS == 3) v += cr[i][j] * (1.f / 2048.f);
+        const f32x4 v = hh[i][j] * G16_UNSCALE;
         const int col = (wn * NW + j) * 16 + (lane & 15);
         *reinterpret_cast<f32x4*>(lds + col * ECS + ((wm * MW + i) * 16 + 4 * (lane >> 4)) * 4) = v;
       }
@@ -448,19 +448,22 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
     }
   }
   u32x4 rv[MW][NW];
+  // (acc * G16_UNSCALE is exact: with a residual the unscaling and the addition are ONE fma with the bits of the two steps)
   if (a.res) {
 #pragma unroll
     for (int i = 0; i < MW; ++i)
 #pragma unroll
       for (int j = 0; j < NW; ++j) rv[i][j] = __builtin_amdgcn_raw_buffer_load_b128(rr_, orr[i][j], 0, 0);
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+      for (int j = 0; j < NW; ++j) hh[i][j] = hh[i][j] * G16_UNSCALE + g16_as_f32x4(rv[i][j]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+      for (int j = 0; j < NW; ++j) hh[i][j] *= G16_UNSCALE;
   }
-#pragma unroll
-  for (int i = 0; i < MW; ++i)
-#pragma unroll
-    for (int j = 0; j < NW; ++j) {
-      if constexpr (TERMS == 3) hh[i][j] += cr[i][j] * (1.f / 2048.f);
-      if (a.res) hh[i][j] += g16_as_f32x4(rv[i][j]);
-    }
   if (a.acc_prev) {
 #pragma unroll
     for (int i = 0; i < MW; ++i)
@@ -600,14 +603,14 @@ __global__ void __launch_bounds__(64 * (ROLES > 4 ? ROLES : 4)) g16_ups(ClConvAr
         Bh[tap][c][m] = *reinterpret_cast<const f16x8*>(a.wh + (blk * 64 + lane) * 8);
         Bl[tap][c][m] = *reinterpret_cast<const f16x8*>(a.wh + ((blk + 1) * 64 + lane) * 8);
       }
-  float bv[NMT];
+  float bvu[NMT];
   int co_of[NMT], ph_of[NMT];
 #pragma unroll
   for (int m = 0; m < NMT; ++m) {
     const int r = (mt0 + m) * 16 + l15;
     ph_of[m] = r / a.Cout;
     co_of[m] = r - ph_of[m] * a.Cout;
-    bv[m] = a.bias ? a.bias[co_of[m]] : 0.f;
+    bvu[m] = a.bias ? a.bias[co_of[m]] * G16_UNSCALE : 0.f;   // (the bias arrives * G16_WSCALE, like the weights)
   }
   const float* xb = a.x + (size_t)b * a.x_bs + kg * 8;
   float* ob = a.out + (size_t)b * a.o_bs;
@@ -632,9 +635,9 @@ __global__ void __launch_bounds__(64 * (ROLES > 4 ? ROLES : 4)) g16_ups(ClConvAr
         raw[tap][c][1] = ok ? *reinterpret_cast<const f32x4*>(p + c * 32 + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
-    f32x4 hh[NMT], cr[NMT];
+    f32x4 hh[NMT];
 #pragma unroll
-    for (int m = 0; m < NMT; ++m) hh[m] = cr[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < NMT; ++m) hh[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int tap = 0; tap < KT; ++tap)
 #pragma unroll
@@ -647,8 +650,8 @@ __global__ void __launch_bounds__(64 * (ROLES > 4 ? ROLES : 4)) g16_ups(ClConvAr
 #pragma unroll
         for (int m = 0; m < NMT; ++m) {
           hh[m] = G16_MFMA(ah, Bh[tap][c][m], hh[m]);
-          cr[m] = G16_MFMA(ah, Bl[tap][c][m], cr[m]);
-          cr[m] = G16_MFMA(al, Bh[tap][c][m], cr[m]);
+          hh[m] = G16_MFMA(ah, Bl[tap][c][m], hh[m]);
+          hh[m] = G16_MFMA(al, Bh[tap][c][m], hh[m]);
         }
       }
     // ---- store: lane = output row r (phase, channel), registers = four consecutive times q
@@ -667,7 +670,7 @@ __global__ void __launch_bounds__(64 * (ROLES > 4 ? ROLES : 4)) g16_ups(ClConvAr
       for (int m = 0; m < NMT; ++m)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
-          et[(4 * kg + jj) * RSF + m * 16 + l15] = hh[m][jj] + cr[m][jj] * (1.f / 2048.f) + bv[m];
+          et[(4 * kg + jj) * RSF + m * 16 + l15] = hh[m][jj] * G16_UNSCALE + bvu[m];
       const int pc = lane % CPR, ql = lane / CPR;
       const int r = mt0 * 16 + 4 * pc;                         // the piece's first row: four consecutive channels of one phase
       const int ph = r / a.Cout, co = r - ph * a.Cout;
@@ -687,7 +690,7 @@ __global__ void __launch_bounds__(64 * (ROLES > 4 ? ROLES : 4)) g16_ups(ClConvAr
         const int q = q0 + 4 * kg + jj;
         const int n = a.phases * q + ph_of[m] - a.ups_p;
         if (q < Nq && n >= 0 && n < T_store)
-          ob[(size_t)n * a.o_ts + co_of[m]] = hh[m][jj] + cr[m][jj] * (1.f / 2048.f) + bv[m];
+          ob[(size_t)n * a.o_ts + co_of[m]] = hh[m][jj] * G16_UNSCALE + bvu[m];
       }
 #endif
   }
@@ -885,7 +888,7 @@ __global__ void __launch_bounds__(64 * NWV, 4) g16_pair(ClPairArgs a) {
   // ---- fragments
   const int xb_lane = q4 * PL + (wave * 32 + l15) * 16;
   const int wa_lane = lane * 16;
-  f32x4 hh[MW][NW], cr[MW][NW];
+  f32x4 hh[MW][NW];
   // MFMAs of one slice: taps [tap0, tap0 + nt) of one chunk; rowstep = dilation of the conv
   auto slice = [&](int slot, int tap0, int nt, int rowstep) {
 #ifdef G16_PRIO
@@ -909,8 +912,8 @@ __global__ void __launch_bounds__(64 * NWV, 4) g16_pair(ClPairArgs a) {
         for (int j = 0; j < NW; ++j) {
           hh[i][j] = G16_MFMA(Ah, Bh[j], hh[i][j]);
           if constexpr (TERMS == 3) {
-            cr[i][j] = G16_MFMA(Al, Bh[j], cr[i][j]);
-            cr[i][j] = G16_MFMA(Ah, Bl[j], cr[i][j]);
+            hh[i][j] = G16_MFMA(Al, Bh[j], hh[i][j]);
+            hh[i][j] = G16_MFMA(Ah, Bl[j], hh[i][j]);
           }
         }
       }
@@ -924,7 +927,7 @@ __global__ void __launch_bounds__(64 * NWV, 4) g16_pair(ClPairArgs a) {
     for (int i = 0; i < MW; ++i) {
       const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 16 * i + 4 * q4);
 #pragma unroll
-      for (int j = 0; j < NW; ++j) { hh[i][j] = bv; cr[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      for (int j = 0; j < NW; ++j) hh[i][j] = bv;
     }
   };
 
@@ -1000,9 +1003,7 @@ __global__ void __launch_bounds__(64 * NWV, 4) g16_pair(ClPairArgs a) {
     const bool valid = tt >= 0 && tt < T;
 #pragma unroll
     for (int i = 0; i < MW; ++i) {
-      f32x4 v;
-      if constexpr (TERMS == 3) v = hh[i][j] + cr[i][j] * (1.f / 2048.f);
-      else v = hh[i][j];
+      const f32x4 v = hh[i][j] * G16_UNSCALE;
       tv[i][j] = valid ? v : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
@@ -1058,9 +1059,7 @@ __global__ void __launch_bounds__(64 * NWV, 4) g16_pair(ClPairArgs a) {
     for (int j = 0; j < NW; ++j) {
       const int r = wave * 32 + 16 * j + l15;
       const int off = r < R2 ? (t0 + r) * C * 4 + (16 * i + 4 * q4) * 4 : G16_OOR;
-      f32x4 v;
-      if constexpr (TERMS == 3) v = hh[i][j] + cr[i][j] * (1.f / 2048.f);
-      else v = hh[i][j];
+      f32x4 v = hh[i][j] * G16_UNSCALE;
       if constexpr (EARLY_RES) v += g16_as_f32x4(res_early[i][j]);
       else v += g16_as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
       if (a.acc_prev) v += g16_as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(ro, off, 0, 0));
@@ -1148,7 +1147,7 @@ hipError_t launch_g16_pair(const ClPairArgs& a, int B, hipStream_t s) {
 //     outside the utterance = the reference's zero padding of EVERY convolution input) are written from registers;
 //   * weights stream through the 3-slot LDS-DMA ring as one sequence of slices over the 2 np convolutions.
 // Per output the arithmetic is that of g16_pair / g16_conv (chunk-major, tap-minor, HH / CROSS / CROSS, bias in the
-// accumulator, (hh + cr / 2048) + x): bit-identical to the pair-per-launch and conv-per-launch paths.
+// accumulator, acc * 2^-8 + x): bit-identical to the pair-per-launch and conv-per-launch paths.
 template <int NCH, int NW, int G, int TERMS, int NWV>
 __global__ void __launch_bounds__(64 * NWV, 2) g16_chain(ClChainArgs a) {
   constexpr int MW = 2 * NCH, C = 32 * NCH, CW = 16 * NW;   // CW = columns per wave
@@ -1260,7 +1259,7 @@ __global__ void __launch_bounds__(64 * NWV, 2) g16_chain(ClChainArgs a) {
   const unsigned wa_lane = lds0 + NCH * XBUF + lane * 16;
   constexpr int gs = G;                         // taps per slice (the last one of a chunk may be shorter)
   f16x8 Ah[2][MW], Al[2][MW], Bh[NW], Bl[NW];
-  f32x4 hh[MW][NW], cr[MW][NW];
+  f32x4 hh[MW][NW];
 
   int n_cur = 0, n_issued = 0, pc_last = 0;     // slice being read; slices requested; my pieces of the youngest one
   auto issue_slice = [&]() {
@@ -1304,21 +1303,21 @@ __global__ void __launch_bounds__(64 * NWV, 2) g16_chain(ClChainArgs a) {
       constexpr int i = decltype(I)::value;
       hh[i][j] = G16_MFMA(Ah[pp][i], Bh[j], hh[i][j]);
       if constexpr (TERMS == 3) {
-        cr[i][j] = G16_MFMA(Al[pp][i], Bh[j], cr[i][j]);
-        cr[i][j] = G16_MFMA(Ah[pp][i], Bl[j], cr[i][j]);
+        hh[i][j] = G16_MFMA(Al[pp][i], Bh[j], hh[i][j]);
+        hh[i][j] = G16_MFMA(Ah[pp][i], Bl[j], hh[i][j]);
       }
     });
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  // one convolution over the image in Xw: dilation `rowstep`, bias b; result in hh / cr.  On entry the image and
+  // one convolution over the image in Xw: dilation `rowstep`, bias b; result in hh.  On entry the image and
   // slice n_cur (the convolution's first) are visible to every wave.
   auto conv = [&](const float* bias, int rowstep) {
 #pragma unroll
     for (int i = 0; i < MW; ++i) {
       const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 16 * i + 4 * q4);
 #pragma unroll
-      for (int j = 0; j < NW; ++j) { hh[i][j] = bv; cr[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      for (int j = 0; j < NW; ++j) hh[i][j] = bv;
     }
     const unsigned xb0 = lds0 + q4 * PL + (GRD + wave * CW + l15 - rowstep * p2) * 16;
     const int steps = NCH * K;
@@ -1362,8 +1361,7 @@ __global__ void __launch_bounds__(64 * NWV, 2) g16_chain(ClChainArgs a) {
     for (int j = 0; j < NW; ++j) asm volatile("" ::"v"(Bh[j]), "v"(Bl[j]));
   };
   auto result = [&](int i, int j) -> f32x4 {
-    if constexpr (TERMS == 3) return hh[i][j] + cr[i][j] * (1.f / 2048.f);
-    else return hh[i][j];
+    return hh[i][j] * G16_UNSCALE;
   };
 
   issue_slice(); issue_slice(); issue_slice();

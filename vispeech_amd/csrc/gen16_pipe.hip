@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_convp(ClConvArgs a) {
   const unsigned xb_lane = lds0 + (lane >> 4) * PL + (wn * NW * 16 + (lane & 15)) * 16;
   const unsigned wa_lane = lds0 + 2 * XBUF + lane * 16 + wm * MW * 2048;
   f16x8 Ah[MW], Al[MW], Bh[NW], Bl[NW];
-  f32x4 hh[MW][NW], cr[MW][NW];
+  f32x4 hh[MW][NW];
   auto acc_init = [&](int cb) {
 #pragma unroll
     for (int i = 0; i < MW; ++i) {
@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_convp(ClConvArgs a) {
       f32x4 bv = {0.f, 0.f, 0.f, 0.f};
       if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + row);
 #pragma unroll
-      for (int j = 0; j < NW; ++j) { hh[i][j] = bv; cr[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      for (int j = 0; j < NW; ++j) hh[i][j] = bv;
     }
   };
 
@@ -193,17 +193,13 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_convp(ClConvArgs a) {
     for (int i = 0; i < MW; ++i)
 #pragma unroll
       for (int j = 0; j < NW; ++j) rv[i][j] = __builtin_amdgcn_raw_buffer_load_b128(rr_, orr[i][j], 0, 0);
-#pragma unroll
-    for (int i = 0; i < MW; ++i)
-#pragma unroll
-      for (int j = 0; j < NW; ++j) hh[i][j] += cr[i][j] * (1.f / 2048.f);
     __builtin_amdgcn_sched_barrier(0);
     if (res_type) g16_vmcnt<0>();     // (what the skipped slice waits of the tile's first two steps rely on)
+    // (acc * G16_UNSCALE is exact: unscaling and residual are ONE fma; without a residual the loads above returned zeros)
 #pragma unroll
     for (int i = 0; i < MW; ++i)
 #pragma unroll
-      for (int j = 0; j < NW; ++j)
-        if (a.res) hh[i][j] += g16_as_f32x4(rv[i][j]);
+      for (int j = 0; j < NW; ++j) hh[i][j] = hh[i][j] * G16_UNSCALE + g16_as_f32x4(rv[i][j]);
     if (a.acc_prev) {
 #pragma unroll
       for (int i = 0; i < MW; ++i)
@@ -307,8 +303,8 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_convp(ClConvArgs a) {
       g16_for<MW>([&](auto I) {
         constexpr int i = decltype(I)::value;
         hh[i][j] = G16_MFMA(Ah[i], Bh[j], hh[i][j]);
-        cr[i][j] = G16_MFMA(Al[i], Bh[j], cr[i][j]);
-        cr[i][j] = G16_MFMA(Ah[i], Bl[j], cr[i][j]);
+        hh[i][j] = G16_MFMA(Al[i], Bh[j], hh[i][j]);
+        hh[i][j] = G16_MFMA(Ah[i], Bl[j], hh[i][j]);
       });
     });
     __builtin_amdgcn_s_setprio(0);

@@ -19,7 +19,7 @@
 //     activated, split and written OVER the dead window with one ds_write_b64 per tile and image; each wave half does
 //     that in the phase in which the other one still multiplies / idles, the ring keeps streaming;
 //   * conv2 on BT - (K - 1) columns from the t images, residual + store as g16_conv's epilogue.
-// The arithmetic per output (chunk-major, tap-minor, HH / CROSS / CROSS, bias in the accumulator, hh + cr / 2048, + x,
+// The arithmetic per output (chunk-major, tap-minor, HH / CROSS / CROSS, bias in the accumulator, acc * 2^-8 + x,
 // + previous, / div) is that of g16_conv / g16_pair: the result is BIT-IDENTICAL to the two-launch path.
 #include "kernels.h"
 
@@ -160,13 +160,13 @@ __global__ void __launch_bounds__(512) g16_pp(ClPairArgs a) {
   const unsigned xb_lane = lds0 + q4 * PL + (wn * NW * 16 + l15) * 16;
   const unsigned wa_lane = lds0 + WIN + lane * 16 + wm * MW * 2048;
   f16x8 Ah[MW], Al[MW], Bh[NW], Bl[NW];
-  f32x4 hh[MW][NW], cr[MW][NW];
+  f32x4 hh[MW][NW];
   auto init_acc = [&](const float* bias) {
 #pragma unroll
     for (int i = 0; i < MW; ++i) {
       const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 64 * wm + 16 * i + 4 * q4);
 #pragma unroll
-      for (int j = 0; j < NW; ++j) { hh[i][j] = bv; cr[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      for (int j = 0; j < NW; ++j) hh[i][j] = bv;
     }
   };
 
@@ -250,8 +250,8 @@ __global__ void __launch_bounds__(512) g16_pp(ClPairArgs a) {
         g16_for<MW>([&](auto I) {
           constexpr int i = decltype(I)::value;
           hh[i][j] = G16_MFMA(Ah[i], Bh[j], hh[i][j]);
-          cr[i][j] = G16_MFMA(Al[i], Bh[j], cr[i][j]);
-          cr[i][j] = G16_MFMA(Ah[i], Bl[j], cr[i][j]);
+          hh[i][j] = G16_MFMA(Al[i], Bh[j], hh[i][j]);
+          hh[i][j] = G16_MFMA(Ah[i], Bl[j], hh[i][j]);
         });
       });
       __builtin_amdgcn_sched_barrier(0);
@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(512) g16_pp(ClPairArgs a) {
     const bool valid = tt >= 0 && tt < T;
 #pragma unroll
     for (int i = 0; i < MW; ++i) {
-      f32x4 v = hh[i][j] + cr[i][j] * (1.f / 2048.f);
+      f32x4 v = hh[i][j] * G16_UNSCALE;
       v = valid ? v : f32x4{0.f, 0.f, 0.f, 0.f};
       f16x4 eh, el;
       g16_split4(v, slope, true, eh, el);
@@ -295,7 +295,7 @@ __global__ void __launch_bounds__(512) g16_pp(ClPairArgs a) {
 #pragma unroll
   for (int i = 0; i < MW; ++i)
 #pragma unroll
-    for (int j = 0; j < NW; ++j) { hh[i][j] = bv2[i]; cr[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int j = 0; j < NW; ++j) hh[i][j] = bv2[i];
   PP_STAMP(21);                     // t tiles written
   G16_BARRIER();
   G16_BARRIER();                    // both halves' tiles are written; the halves are one phase apart again
@@ -313,7 +313,7 @@ __global__ void __launch_bounds__(512) g16_pp(ClPairArgs a) {
   // nothing hides it).  The conv2 tile (cross accumulator folded) goes to the dead window as [column][128 channels] fp32
   // (528-byte column stride: conflict-free 16-byte writes), then a wave owns whole column PAIRS: 32 lanes x 16 B = one
   // column's 512 B, two adjacent columns = 1 KiB of the channels-last tensor -- residual, previous sum and result alike.
-  // Same arithmetic in the same order ((hh + cr / 2048) + x [+ previous] [/ div]): bit-identical.
+  // Same arithmetic in the same order (acc * 2^-8 + x [+ previous] [/ div]): bit-identical.
   // Nobody reads the window any more: the first half has passed the barrier behind its last MFMA phase, which the second
   // half reached only after its last fragment reads.
   constexpr int ECS = C * 4 + 16;                 // column stride in the LDS tile
@@ -322,7 +322,7 @@ __global__ void __launch_bounds__(512) g16_pp(ClPairArgs a) {
   for (int i = 0; i < MW; ++i)
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
-      const f32x4 v = hh[i][j] + cr[i][j] * (1.f / 2048.f);
+      const f32x4 v = hh[i][j] * G16_UNSCALE;
       const int col = wn * NW * 16 + 16 * j + l15;
       *reinterpret_cast<f32x4*>(Xw + col * ECS + (64 * wm + 16 * i + 4 * q4) * 4) = v;
     }
@@ -376,7 +376,7 @@ __global__ void __launch_bounds__(512) g16_pp(ClPairArgs a) {
   for (int i = 0; i < MW; ++i)
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
-      hh[i][j] += cr[i][j] * (1.f / 2048.f);
+      hh[i][j] *= G16_UNSCALE;
       hh[i][j] += g16_as_f32x4(rv[i][j]);
     }
   if (a.acc_prev) {

@@ -116,13 +116,12 @@ __global__ void __launch_bounds__(512) g16_rc(ClChainArgs a, int total_tiles) {
     nBl = g16_lds_read<RC_IMG>(baddr);
   };
   auto conv_group = [&](auto P, auto LAST, unsigned baddr, unsigned step, unsigned bnext, unsigned bias_a, f32x4& hh0,
-                        f32x4& hh1, f32x4& cr0, f32x4& cr1) {
+                        f32x4& hh1) {
     constexpr int p = decltype(P)::value;
     constexpr bool last = decltype(LAST)::value;
     // (the bias straight into the accumulators: requested behind the group's primed fragments, it is the youngest read)
     hh0 = __builtin_bit_cast(f32x4, g16_lds_read<0>(bias_a));
     hh1 = __builtin_bit_cast(f32x4, g16_lds_read<64>(bias_a));
-    cr0 = f32x4{0.f, 0.f, 0.f, 0.f}; cr1 = cr0;
     if constexpr (RC_PRIO) __builtin_amdgcn_s_setprio(1);
     f16x8 Bh[2], Bl[2];
     Bh[0] = nBh; Bl[0] = nBl;
@@ -142,10 +141,10 @@ __global__ void __launch_bounds__(512) g16_rc(ClChainArgs a, int total_tiles) {
       __builtin_amdgcn_sched_barrier(0);
       hh0 = G16_MFMA(Wh[p][tap][0], Bh[cur], hh0);
       hh1 = G16_MFMA(Wh[p][tap][1], Bh[cur], hh1);
-      cr0 = G16_MFMA(Wl[p][tap][0], Bh[cur], cr0);
-      cr1 = G16_MFMA(Wl[p][tap][1], Bh[cur], cr1);
-      cr0 = G16_MFMA(Wh[p][tap][0], Bl[cur], cr0);
-      cr1 = G16_MFMA(Wh[p][tap][1], Bl[cur], cr1);
+      hh0 = G16_MFMA(Wl[p][tap][0], Bh[cur], hh0);
+      hh1 = G16_MFMA(Wl[p][tap][1], Bh[cur], hh1);
+      hh0 = G16_MFMA(Wh[p][tap][0], Bl[cur], hh0);
+      hh1 = G16_MFMA(Wh[p][tap][1], Bl[cur], hh1);
       __builtin_amdgcn_sched_barrier(0);
     });
     if constexpr (RC_PRIO) __builtin_amdgcn_s_setprio(0);
@@ -272,12 +271,12 @@ __global__ void __launch_bounds__(512) g16_rc(ClChainArgs a, int total_tiles) {
     char* const ti = TI + (j & 1) * RC_BUF;
     g16_for<RC_G>([&](auto GG) {
       constexpr int g = decltype(GG)::value;
-      f32x4 hh0, hh1, cr0, cr1;
+      f32x4 hh0, hh1;
       conv_group(P, std::integral_constant<bool, g + 1 == RC_G>{}, xb0 + g * 256, (unsigned)d * 16, xb0 + (g + 1) * 256, bias_a,
-                 hh0, hh1, cr0, cr1);
+                 hh0, hh1);
       const int col = wr * RC_CW + 16 * g + l15;
       const int t = at.tb + col;
-      write_image(MASK, ti, col, q4, t, Tu, hh0 + cr0 * (1.f / 2048.f), hh1 + cr1 * (1.f / 2048.f));
+      write_image(MASK, ti, col, q4, t, Tu, hh0 * G16_UNSCALE, hh1 * G16_UNSCALE);
     });
   };
   auto conv2_item_m = [&](auto P, auto MASK, TileAt at, int m, int j, int ln, f32x4 (&xr)[RC_G][2]) {
@@ -315,12 +314,11 @@ __global__ void __launch_bounds__(512) g16_rc(ClChainArgs a, int total_tiles) {
     g16_for<RC_G>([&](auto GG) {
       constexpr int g = decltype(GG)::value;
       if constexpr (p == RC_NP - 1 && ACC && g + 1 < RC_G) fetch_prv(std::integral_constant<int, g + 1>{});
-      f32x4 hh0, hh1, cr0, cr1;
-      conv_group(P, std::integral_constant<bool, g + 1 == RC_G>{}, tb0 + g * 256, 16u, tb0 + (g + 1) * 256, bias_a, hh0, hh1,
-                 cr0, cr1);
+      f32x4 hh0, hh1;
+      conv_group(P, std::integral_constant<bool, g + 1 == RC_G>{}, tb0 + g * 256, 16u, tb0 + (g + 1) * 256, bias_a, hh0, hh1);
       const int col = wr * RC_CW + 16 * g + l15;
       const int t = at.tb + col;
-      f32x4 v0 = hh0 + cr0 * (1.f / 2048.f), v1 = hh1 + cr1 * (1.f / 2048.f);
+      f32x4 v0 = hh0 * G16_UNSCALE, v1 = hh1 * G16_UNSCALE;
       v0 += xr[g][0];
       v1 += xr[g][1];
       if constexpr (p + 1 < RC_NP) {

@@ -1,6 +1,6 @@
 // g16_rw: fused ResBlock1 conv PAIR of the 32-channel stage (reference modules.py:210-223) with the WEIGHTS IN REGISTERS
 // (round 4).  Same arithmetic per output as g16_pair / g16_conv (tap-minor, HH / CROSS / CROSS per step, bias in the
-// accumulator, (hh + cr / 2048) + x) -- bit-identical results -- but none of the ring kernel's hand-shakes:
+// accumulator, acc * 2^-8 + x) -- bit-identical results -- but none of the ring kernel's hand-shakes:
 //
 //   * a 32-channel convolution's whole weight image is K x 2 m-tiles x (hi | lo) A fragments = 16 K registers per lane
 //     (112 at K = 7, 176 at K = 11).  Waves 0-3 of a block hold conv1's, waves 4-7 conv2's, for the block's whole life:
@@ -144,8 +144,7 @@ __global__ void __launch_bounds__(512) g16_rw(ClPairArgs a, int total_tiles) {
     }
     nBh = g16_lds_read<0>(baddr);
   };
-  auto conv_group = [&](auto IMG, auto LAST, unsigned baddr, unsigned step, unsigned bnext, f32x4& hh0, f32x4& hh1,
-                        f32x4& cr0, f32x4& cr1) {
+  auto conv_group = [&](auto IMG, auto LAST, unsigned baddr, unsigned step, unsigned bnext, f32x4& hh0, f32x4& hh1) {
     constexpr int img = decltype(IMG)::value;
     constexpr bool last = decltype(LAST)::value;
     if constexpr (INPLACE) {
@@ -154,7 +153,6 @@ __global__ void __launch_bounds__(512) g16_rw(ClPairArgs a, int total_tiles) {
     } else {
       hh0 = nh0; hh1 = nh1;
     }
-    cr0 = f32x4{0.f, 0.f, 0.f, 0.f}; cr1 = cr0;
     __builtin_amdgcn_s_setprio(1);                           // (the MFMA stream wins the SIMD's issue port; the partner's vector
                                                              //  work fills the gaps the matrix pipe leaves)
     if constexpr (!INPLACE) {
@@ -177,10 +175,10 @@ __global__ void __launch_bounds__(512) g16_rw(ClPairArgs a, int total_tiles) {
         __builtin_amdgcn_sched_barrier(0);
         hh0 = G16_MFMA(Wh[tap][0], Bh[cur], hh0);
         hh1 = G16_MFMA(Wh[tap][1], Bh[cur], hh1);
-        cr0 = G16_MFMA(Wl[tap][0], Bh[cur], cr0);
-        cr1 = G16_MFMA(Wl[tap][1], Bh[cur], cr1);
-        cr0 = G16_MFMA(Wh[tap][0], Bl[cur], cr0);
-        cr1 = G16_MFMA(Wh[tap][1], Bl[cur], cr1);
+        hh0 = G16_MFMA(Wl[tap][0], Bh[cur], hh0);
+        hh1 = G16_MFMA(Wl[tap][1], Bh[cur], hh1);
+        hh0 = G16_MFMA(Wh[tap][0], Bl[cur], hh0);
+        hh1 = G16_MFMA(Wh[tap][1], Bl[cur], hh1);
         __builtin_amdgcn_sched_barrier(0);
       });
     } else {
@@ -193,15 +191,15 @@ __global__ void __launch_bounds__(512) g16_rw(ClPairArgs a, int total_tiles) {
         __builtin_amdgcn_sched_barrier(0);
         hh0 = G16_MFMA(Wh[tap][0], Bh, hh0);
         hh1 = G16_MFMA(Wh[tap][1], Bh, hh1);
-        cr0 = G16_MFMA(Wl[tap][0], Bh, cr0);
-        cr1 = G16_MFMA(Wl[tap][1], Bh, cr1);
+        hh0 = G16_MFMA(Wl[tap][0], Bh, hh0);
+        hh1 = G16_MFMA(Wl[tap][1], Bh, hh1);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (more) Bh = g16_lds_read<0>(baddr + (tap + 1) * step);
         else if constexpr (!last) { prime_hi(bnext); Bh = nBh; }
         g16_lgkmcnt<(more || !last) ? 1 : 0>();              // the low image of this tap: older than the read just requested
         __builtin_amdgcn_sched_barrier(0);
-        cr0 = G16_MFMA(Wh[tap][0], Bl, cr0);
-        cr1 = G16_MFMA(Wh[tap][1], Bl, cr1);
+        hh0 = G16_MFMA(Wh[tap][0], Bl, hh0);
+        hh1 = G16_MFMA(Wh[tap][1], Bl, hh1);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (more) Bl = g16_lds_read<img>(baddr + (tap + 1) * step);
         else if constexpr (!last) Bl = g16_lds_read<img>(bnext);
@@ -348,15 +346,15 @@ __global__ void __launch_bounds__(512) g16_rw(ClPairArgs a, int total_tiles) {
         const bool inside = t0 - p2 >= 0 && t0 - p2 + RW_BT <= Tc;    // (uniform: every conv1 column of the tile is in the utterance)
         g16_for<RW_G>([&](auto GG) {
           constexpr int g = decltype(GG)::value;
-          f32x4 hh0, hh1, cr0, cr1;
+          f32x4 hh0, hh1;
           conv_group(std::integral_constant<int, RW_XIMG>{}, std::integral_constant<bool, g + 1 == RW_G>{}, xb0 + g * 256,
-                     (unsigned)a.dil * 16, xb0 + (g + 1) * 256, hh0, hh1, cr0, cr1);
+                     (unsigned)a.dil * 16, xb0 + (g + 1) * 256, hh0, hh1);
           RW_STAMP(3 + g);
           // activated, split tile -> t image; columns outside the utterance are conv2's zero padding.  A lane's four
           // channels 16 i + 4 q4 .. + 3 sit in plane 2 i + (q4 >> 1) at byte 8 (q4 & 1) of the row's 16
           const int col = wr * RW_CW + 16 * g + l15;
           const int tt = t0 - p2 + col;
-          f32x4 t0v = hh0 + cr0 * (1.f / 2048.f), t1v = hh1 + cr1 * (1.f / 2048.f);
+          f32x4 t0v = hh0 * G16_UNSCALE, t1v = hh1 * G16_UNSCALE;
           if (!inside && !(tt >= 0 && tt < Tc)) { t0v = f32x4{0.f, 0.f, 0.f, 0.f}; t1v = t0v; }
           if (!(diag & 8)) {
             f16x4 eh, el;
@@ -419,12 +417,12 @@ __global__ void __launch_bounds__(512) g16_rw(ClPairArgs a, int total_tiles) {
           constexpr int g = decltype(GG)::value, s = g & 1;
           if constexpr (!AHEAD) fetch(GG);
           else if constexpr (g + 1 < RW_G) fetch(std::integral_constant<int, g + 1>{});
-          f32x4 hh0, hh1, cr0, cr1;
+          f32x4 hh0, hh1;
           conv_group(std::integral_constant<int, RW_TIMG>{}, std::integral_constant<bool, g + 1 == RW_G>{}, tb0 + g * 256, 16u,
-                     tb0 + (g + 1) * 256, hh0, hh1, cr0, cr1);
+                     tb0 + (g + 1) * 256, hh0, hh1);
           RW_STAMP(3 + g);
           const int off = (diag & 2) ? G16_OOR : off_of(g);
-          f32x4 v0 = hh0 + cr0 * (1.f / 2048.f), v1 = hh1 + cr1 * (1.f / 2048.f);
+          f32x4 v0 = hh0 * G16_UNSCALE, v1 = hh1 * G16_UNSCALE;
           v0 += g16_as_f32x4(res[s][0]);
           v1 += g16_as_f32x4(res[s][1]);
           if constexpr (ACC) { v0 += g16_as_f32x4(prv[s][0]); v1 += g16_as_f32x4(prv[s][1]); }

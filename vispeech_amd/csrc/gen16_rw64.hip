@@ -16,7 +16,7 @@
 //     ahead (wave-private 1 KiB pieces of 4 rows x 64 channels), split by the wave that requested it -- conv2 waves at the
 //     top of an iteration, conv1 waves at the bottom, so that the two waves of a SIMD are out of step;
 //   * the arithmetic per output (chunk-major, tap-minor, HH / CROSS / CROSS per step, bias in the accumulator,
-//     (hh + cr / 2048) + x) is that of g16_pair / g16_conv: results are BIT-IDENTICAL (tests/test_cl_ops.py,
+//     acc * 2^-8 + x) is that of g16_pair / g16_conv: results are BIT-IDENTICAL (tests/test_cl_ops.py,
 //     tests/test_hip_parity.py: VSP_PAIR=ring keeps the LDS-ring kernel as the second implementation).
 //
 // LDS: x images 2 x 28 KB, t images 2 x 28 KB, staging 28 KB, biases = 141 KB: one block of 8 waves per CU.
@@ -118,10 +118,8 @@ __global__ void __launch_bounds__(512) g16_rw64(ClPairArgs a, int total_tiles) {
       nBl1 = g16_lds_read<R6_IMG>(baddr + prime_step);
     }
   };
-  auto conv_group = [&](auto LAST, unsigned baddr, unsigned step, unsigned bnext, f32x4& hh0, f32x4& hh1, f32x4& cr0,
-                        f32x4& cr1) {
+  auto conv_group = [&](auto LAST, unsigned baddr, unsigned step, unsigned bnext, f32x4& hh0, f32x4& hh1) {
     constexpr bool last = decltype(LAST)::value;
-    cr0 = f32x4{0.f, 0.f, 0.f, 0.f}; cr1 = cr0;
     __builtin_amdgcn_s_setprio(1);
     if constexpr (R6_AHEAD == 2) {
       f16x8 Bh[3], Bl[3];
@@ -146,10 +144,10 @@ __global__ void __launch_bounds__(512) g16_rw64(ClPairArgs a, int total_tiles) {
         if constexpr (s == 0) { hh0 = nh0; hh1 = nh1; }            // (the primed bias: landed, behind the wait above)
         hh0 = G16_MFMA(Wh[s][0], Bh[cur], hh0);
         hh1 = G16_MFMA(Wh[s][1], Bh[cur], hh1);
-        cr0 = G16_MFMA(Wl[s][0], Bh[cur], cr0);
-        cr1 = G16_MFMA(Wl[s][1], Bh[cur], cr1);
-        cr0 = G16_MFMA(Wh[s][0], Bl[cur], cr0);
-        cr1 = G16_MFMA(Wh[s][1], Bl[cur], cr1);
+        hh0 = G16_MFMA(Wl[s][0], Bh[cur], hh0);
+        hh1 = G16_MFMA(Wl[s][1], Bh[cur], hh1);
+        hh0 = G16_MFMA(Wh[s][0], Bl[cur], hh0);
+        hh1 = G16_MFMA(Wh[s][1], Bl[cur], hh1);
         __builtin_amdgcn_sched_barrier(0);
       });
     } else {
@@ -173,10 +171,10 @@ __global__ void __launch_bounds__(512) g16_rw64(ClPairArgs a, int total_tiles) {
         if constexpr (s == 0) { hh0 = nh0; hh1 = nh1; }            // (the primed bias: landed, behind the wait above)
         hh0 = G16_MFMA(Wh[s][0], Bh[cur], hh0);
         hh1 = G16_MFMA(Wh[s][1], Bh[cur], hh1);
-        cr0 = G16_MFMA(Wl[s][0], Bh[cur], cr0);
-        cr1 = G16_MFMA(Wl[s][1], Bh[cur], cr1);
-        cr0 = G16_MFMA(Wh[s][0], Bl[cur], cr0);
-        cr1 = G16_MFMA(Wh[s][1], Bl[cur], cr1);
+        hh0 = G16_MFMA(Wl[s][0], Bh[cur], hh0);
+        hh1 = G16_MFMA(Wl[s][1], Bh[cur], hh1);
+        hh0 = G16_MFMA(Wh[s][0], Bl[cur], hh0);
+        hh1 = G16_MFMA(Wh[s][1], Bl[cur], hh1);
         __builtin_amdgcn_sched_barrier(0);
       });
     }
@@ -305,14 +303,14 @@ __global__ void __launch_bounds__(512) g16_rw64(ClPairArgs a, int total_tiles) {
         const bool inside = t0 - p2 >= 0 && t0 - p2 + R6_BT <= Tc;
         g16_for<R6_G>([&](auto GG) {
           constexpr int g = decltype(GG)::value;
-          f32x4 hh0, hh1, cr0, cr1;
+          f32x4 hh0, hh1;
           conv_group(std::integral_constant<bool, g + 1 == R6_G>{}, xb0 + g * 256, (unsigned)a.dil * 16, xb0 + (g + 1) * 256,
-                     hh0, hh1, cr0, cr1);
+                     hh0, hh1);
           // activated, split tile -> t image (chunk rh); columns outside the utterance are conv2's zero padding.  A lane's
           // four channels 16 i + 4 q4 .. + 3 of the chunk sit in plane 2 i + (q4 >> 1) at byte 8 (q4 & 1) of the row's 16
           const int col = chh * R6_CW + 16 * g + l15;
           const int tt = t0 - p2 + col;
-          f32x4 t0v = hh0 + cr0 * (1.f / 2048.f), t1v = hh1 + cr1 * (1.f / 2048.f);
+          f32x4 t0v = hh0 * G16_UNSCALE, t1v = hh1 * G16_UNSCALE;
           if (!inside && !(tt >= 0 && tt < Tc)) { t0v = f32x4{0.f, 0.f, 0.f, 0.f}; t1v = t0v; }
           f16x4 eh, el;
           char* dst = ti + (q4 >> 1) * R6_PL + col * 16 + 8 * (q4 & 1);
@@ -372,10 +370,10 @@ __global__ void __launch_bounds__(512) g16_rw64(ClPairArgs a, int total_tiles) {
         g16_for<R6_G>([&](auto GG) {
           constexpr int g = decltype(GG)::value, s = g & 1;
           if constexpr (g + 1 < R6_G) fetch(std::integral_constant<int, g + 1>{});
-          f32x4 hh0, hh1, cr0, cr1;
-          conv_group(std::integral_constant<bool, g + 1 == R6_G>{}, tb0 + g * 256, 16u, tb0 + (g + 1) * 256, hh0, hh1, cr0, cr1);
+          f32x4 hh0, hh1;
+          conv_group(std::integral_constant<bool, g + 1 == R6_G>{}, tb0 + g * 256, 16u, tb0 + (g + 1) * 256, hh0, hh1);
           const int off = off_of(g);
-          f32x4 v0 = hh0 + cr0 * (1.f / 2048.f), v1 = hh1 + cr1 * (1.f / 2048.f);
+          f32x4 v0 = hh0 * G16_UNSCALE, v1 = hh1 * G16_UNSCALE;
           v0 += g16_as_f32x4(res[s][0]);
           v1 += g16_as_f32x4(res[s][1]);
           if constexpr (ACC) { v0 += g16_as_f32x4(prv[s][0]); v1 += g16_as_f32x4(prv[s][1]); }

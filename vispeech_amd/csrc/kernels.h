@@ -66,6 +66,11 @@ size_t packed_conv_floats(int M, int Cin, int K);
 void pack_conv_weights(float* dst, int M, int Cin, int K, const float* dense /* [M][Cin][K] */);
 void pack_conv_weights_f16s(float* dst, int M, int Cin, int K, const float* dense /* [M][Cin][K] */);
 
+// The channels-last split-f16 kernels take their weights AND biases * G16_WSCALE and unscale every result by G16_UNSCALE
+// (powers of two: exact; g16_common.h "ONE accumulator per tile"): pack_g16_weights scales the weights itself, whoever
+// fills a bias array for these kernels (weights.cpp, upload_cl_conv in api.hip) scales the bias.
+constexpr float G16_WSCALE = 256.f, G16_UNSCALE = 1.f / 256.f;
+
 // ------------------------------------------------------------------------------------------
 // channels-last split-f16 vocoder conv (gen16.hip): x [B][T][Cin], out [B][T][Cout]
 struct ClConvArgs {

@@ -406,7 +406,7 @@ struct Filler {
           for (int t = 0; t < c.K; ++t) dense[(((size_t)ph * c.Cout + co) * c.Cin + ci) * c.K + t] = w(ph, co, ci, t);
     // [phase][co][ci][tap] is [row = phase * Cout + co][ci][tap]: the stacked-phase form gen16.hip multiplies
     pack_g16_weights(reinterpret_cast<uint16_t*>(arena.data() + c.wg), c.phases * c.Cout, c.Cin, c.K, dense.data());
-    for (int co = 0; co < c.Cout; ++co) arena[c.b + co] = b(co);
+    for (int co = 0; co < c.Cout; ++co) arena[c.b + co] = b(co) * G16_WSCALE;   // (kernels.h: the bias rides in the scaled accumulator)
   }
   void clconv_plain(const ClConv& c, const std::string& wname, const std::string& bname) {
     const HostTensor* W = get(wname);
