@@ -393,9 +393,9 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
     for (int i = 0; i < MW; ++i)
 #pragma unroll
       for (int j = 0; j < NW; ++j) {
-        const f32x4 v = hh[i][j] * G16_UNSCALE;
+        // (the accumulator as it is: the unscaling is folded into the residual's fma below)
         const int col = (wn * NW + j) * 16 + (lane & 15);
-        *reinterpret_cast<f32x4*>(lds + col * ECS + ((wm * MW + i) * 16 + 4 * (lane >> 4)) * 4) = v;
+        *reinterpret_cast<f32x4*>(lds + col * ECS + ((wm * MW + i) * 16 + 4 * (lane >> 4)) * 4) = hh[i][j];
       }
     G16_BARRIER();
     const int lc = lane % LPC, cw = lane / LPC;
@@ -422,7 +422,8 @@ __global__ void __launch_bounds__(64 * WM * WN) g16_conv(ClConvArgs a) {
       for (int u = 0; u < NBT; ++u) {
         const int col = (wave * NIT + u0 + u) * CPI + cw;
         f32x4 v = *reinterpret_cast<const f32x4*>(lds + col * ECS + lc * 16);
-        if (a.res) v += g16_as_f32x4(rv[u]);
+        if (a.res) v = v * G16_UNSCALE + g16_as_f32x4(rv[u]);     // (exact product: the bits of unscale-then-add)
+        else v *= G16_UNSCALE;
         if (a.acc_prev) v += g16_as_f32x4(pv[u]);
         g16_div(v, a.div);
         __builtin_amdgcn_raw_buffer_store_b128(g16_as_u32x4(v), ro, eo[u], 0, 0);
@@ -1000,12 +1001,9 @@ __global__ void __launch_bounds__(64 * NWV, 4) g16_pair(ClPairArgs a) {
 #pragma unroll
   for (int j = 0; j < NW; ++j) {
     const int tt = t0 - p2 + wave * 32 + 16 * j + l15;
-    const bool valid = tt >= 0 && tt < T;
+    const float f = tt >= 0 && tt < T ? G16_UNSCALE : 0.f;   // (the unscaling and the zero padding of columns outside the utterance in ONE multiply: the factor is per column)
 #pragma unroll
-    for (int i = 0; i < MW; ++i) {
-      const f32x4 v = hh[i][j] * G16_UNSCALE;
-      tv[i][j] = valid ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int i = 0; i < MW; ++i) tv[i][j] = hh[i][j] * f;
   }
 
   G16_STAMPT(20);

@@ -279,11 +279,10 @@ __global__ void __launch_bounds__(512) g16_pp(ClPairArgs a) {
   for (int j = 0; j < NW; ++j) {
     const int row = wn * NW * 16 + 16 * j + l15;
     const int tt = t0 - p2 + row;
-    const bool valid = tt >= 0 && tt < T;
+    const float f = tt >= 0 && tt < T ? G16_UNSCALE : 0.f;   // (the unscaling and the zero padding of columns outside the utterance in ONE multiply: the factor is per column)
 #pragma unroll
     for (int i = 0; i < MW; ++i) {
-      f32x4 v = hh[i][j] * G16_UNSCALE;
-      v = valid ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 v = hh[i][j] * f;
       f16x4 eh, el;
       g16_split4(v, slope, true, eh, el);
       // (asm stores: in front of a visible LDS store hipcc drains vmcnt -- the two conv2 slices in flight)
@@ -322,9 +321,9 @@ __global__ void __launch_bounds__(512) g16_pp(ClPairArgs a) {
   for (int i = 0; i < MW; ++i)
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
-      const f32x4 v = hh[i][j] * G16_UNSCALE;
+      // (the accumulator as it is: the unscaling is folded into the residual's fma below)
       const int col = wn * NW * 16 + 16 * j + l15;
-      *reinterpret_cast<f32x4*>(Xw + col * ECS + (64 * wm + 16 * i + 4 * q4) * 4) = v;
+      *reinterpret_cast<f32x4*>(Xw + col * ECS + (64 * wm + 16 * i + 4 * q4) * 4) = hh[i][j];
     }
   G16_BARRIER();
   {
@@ -347,7 +346,7 @@ __global__ void __launch_bounds__(512) g16_pp(ClPairArgs a) {
     for (int u = 0; u < NPAIR; ++u) {
       const int col = 2 * (wave * NPAIR + u) + half;
       f32x4 v = *reinterpret_cast<const f32x4*>(Xw + col * ECS + l31 * 16);
-      v += g16_as_f32x4(rv[u]);
+      v = v * G16_UNSCALE + g16_as_f32x4(rv[u]);          // (exact product: the bits of unscale-then-add)
       if (a.acc_prev) v += g16_as_f32x4(pv[u]);
       g16_div(v, a.div);
       __builtin_amdgcn_raw_buffer_store_b128(g16_as_u32x4(v), ro, eo[u], 0, 0);

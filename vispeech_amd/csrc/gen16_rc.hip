@@ -225,10 +225,12 @@ __global__ void __launch_bounds__(512) g16_rc(ClChainArgs a, int total_tiles) {
   // an activated, split D-layout tile pair (channels 4 q4 .. + 3 and 16 + 4 q4 .. + 3 of column `col`) -> image; columns
   // outside the utterance are the next convolution's zero padding.  A lane's four channels 16 i + 4 q4 .. + 3 sit in plane
   // 2 i + (q4 >> 1) at byte 8 (q4 & 1) of the row's 16
-  auto write_image = [&](auto MASK, char* img, int col, int q4, int t, int T, f32x4 v0, f32x4 v1) {
-    if constexpr (decltype(MASK)::value) {
-      if (!(t >= 0 && t < T)) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
-    }
+  // (scale: G16_UNSCALE for accumulators, 1 for finished values -- the unscaling and the zero padding of columns outside
+  // the utterance are ONE multiply, the factor is per column)
+  auto write_image = [&](auto MASK, char* img, int col, int q4, int t, int T, f32x4 a0, f32x4 a1, float scale) {
+    float f = scale;
+    if constexpr (decltype(MASK)::value) f = t >= 0 && t < T ? scale : 0.f;
+    const f32x4 v0 = a0 * f, v1 = a1 * f;
     f16x4 eh, el;
     char* dst = img + (q4 >> 1) * RC_PL + (RC_GRD + col) * 16 + 8 * (q4 & 1);
     g16_split4(v0, slope, true, eh, el);
@@ -276,7 +278,7 @@ __global__ void __launch_bounds__(512) g16_rc(ClChainArgs a, int total_tiles) {
                  hh0, hh1);
       const int col = wr * RC_CW + 16 * g + l15;
       const int t = at.tb + col;
-      write_image(MASK, ti, col, q4, t, Tu, hh0 * G16_UNSCALE, hh1 * G16_UNSCALE);
+      write_image(MASK, ti, col, q4, t, Tu, hh0, hh1, G16_UNSCALE);
     });
   };
   auto conv2_item_m = [&](auto P, auto MASK, TileAt at, int m, int j, int ln, f32x4 (&xr)[RC_G][2]) {
@@ -323,7 +325,7 @@ __global__ void __launch_bounds__(512) g16_rc(ClChainArgs a, int total_tiles) {
       v1 += xr[g][1];
       if constexpr (p + 1 < RC_NP) {
         xr[g][0] = v0; xr[g][1] = v1;                           // x_{p+1}
-        write_image(MASK, xw, col, q4, t, Tu, v0, v1);    // ... and the next pass's input image
+        write_image(MASK, xw, col, q4, t, Tu, v0, v1, 1.f);    // ... and the next pass's input image
       } else {
         const int off = (col >= H && col < H + R && t < Tu) ? (t * 32 + 4 * q4) * 4 : G16_OOR;
         if constexpr (ACC) { v0 += g16_as_f32x4(prv[g & 1][0]); v1 += g16_as_f32x4(prv[g & 1][1]); }

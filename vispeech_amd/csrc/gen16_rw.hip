@@ -354,8 +354,8 @@ __global__ void __launch_bounds__(512) g16_rw(ClPairArgs a, int total_tiles) {
           // channels 16 i + 4 q4 .. + 3 sit in plane 2 i + (q4 >> 1) at byte 8 (q4 & 1) of the row's 16
           const int col = wr * RW_CW + 16 * g + l15;
           const int tt = t0 - p2 + col;
-          f32x4 t0v = hh0 * G16_UNSCALE, t1v = hh1 * G16_UNSCALE;
-          if (!inside && !(tt >= 0 && tt < Tc)) { t0v = f32x4{0.f, 0.f, 0.f, 0.f}; t1v = t0v; }
+          const float f = inside || (tt >= 0 && tt < Tc) ? G16_UNSCALE : 0.f;   // (the unscaling and the zero padding of columns outside the utterance in ONE multiply: the factor is per column)
+          const f32x4 t0v = hh0 * f, t1v = hh1 * f;
           if (!(diag & 8)) {
             f16x4 eh, el;
             char* dst = ti + (q4 >> 1) * RW_PLT + col * 16 + 8 * (q4 & 1);

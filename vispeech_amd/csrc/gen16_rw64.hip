@@ -310,8 +310,8 @@ __global__ void __launch_bounds__(512) g16_rw64(ClPairArgs a, int total_tiles) {
           // four channels 16 i + 4 q4 .. + 3 of the chunk sit in plane 2 i + (q4 >> 1) at byte 8 (q4 & 1) of the row's 16
           const int col = chh * R6_CW + 16 * g + l15;
           const int tt = t0 - p2 + col;
-          f32x4 t0v = hh0 * G16_UNSCALE, t1v = hh1 * G16_UNSCALE;
-          if (!inside && !(tt >= 0 && tt < Tc)) { t0v = f32x4{0.f, 0.f, 0.f, 0.f}; t1v = t0v; }
+          const float f = inside || (tt >= 0 && tt < Tc) ? G16_UNSCALE : 0.f;   // (unscaling and zero padding in one multiply)
+          const f32x4 t0v = hh0 * f, t1v = hh1 * f;
           f16x4 eh, el;
           char* dst = ti + (q4 >> 1) * R6_PL + col * 16 + 8 * (q4 & 1);
           g16_split4(t0v, slope, true, eh, el);

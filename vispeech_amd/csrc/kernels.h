@@ -69,7 +69,11 @@ void pack_conv_weights_f16s(float* dst, int M, int Cin, int K, const float* dens
 // The channels-last split-f16 kernels take their weights AND biases * G16_WSCALE and unscale every result by G16_UNSCALE
 // (powers of two: exact; g16_common.h "ONE accumulator per tile"): pack_g16_weights scales the weights itself, whoever
 // fills a bias array for these kernels (weights.cpp, upload_cl_conv in api.hip) scales the bias.
-constexpr float G16_WSCALE = 256.f, G16_UNSCALE = 1.f / 256.f;
+#ifndef G16_WSCALE_V          // (timing experiments only: -DG16_WSCALE_V=1.f -DG16_UNSCALE_V=1.f is the unscaled form)
+#define G16_WSCALE_V 256.f
+#define G16_UNSCALE_V (1.f / 256.f)
+#endif
+constexpr float G16_WSCALE = G16_WSCALE_V, G16_UNSCALE = G16_UNSCALE_V;
 
 // ------------------------------------------------------------------------------------------
 // channels-last split-f16 vocoder conv (gen16.hip): x [B][T][Cin], out [B][T][Cout]
