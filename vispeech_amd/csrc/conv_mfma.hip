@@ -54,7 +54,7 @@ void pack_conv_weights(float* dst, int M, int Cin, int K, const float* dense) {
 
 // Split-f16 variant of the same packing (F16S kernels below): the 4 KiB block of one (m-tile, chunk,
 // tap) holds [k-step 0..1][hi, lo][lane][8 halfs]; lane l = row (l & 31), k = 16*ks + 8*(l >> 5) + j.
-// w = wh + wl * 2^-11 exactly as in gen16.hip.
+// w * 2^8 = wh + wl exactly as in gen16.hip (round 5: unscaled lo parts, weights * G16_WSCALE, ONE accumulator).
 void pack_conv_weights_f16s(float* dst_f, int M, int Cin, int K, const float* dense) {
   const int nc = (Cin + CONV_CK - 1) / CONV_CK;
   std::memset(dst_f, 0, packed_conv_floats(M, Cin, K) * sizeof(float));
@@ -65,9 +65,9 @@ void pack_conv_weights_f16s(float* dst_f, int M, int Cin, int K, const float* de
       const int chunk = ci / CONV_CK, cc = ci % CONV_CK;
       const int ks = cc >> 4, hh = (cc >> 3) & 1, j = cc & 7, lane = rin + 32 * hh;
       for (int tap = 0; tap < K; ++tap) {
-        const float w = dense[((size_t)row * Cin + ci) * K + tap];
+        const float w = dense[((size_t)row * Cin + ci) * K + tap] * G16_WSCALE;   // (kernels.h: exact; keeps lo normal)
         const _Float16 h = (_Float16)w;
-        const _Float16 l = (_Float16)((w - (float)h) * 2048.f);
+        const _Float16 l = (_Float16)(w - (float)h);
         const size_t blk = (((size_t)mtile * nc + chunk) * K + tap) * 2048;   // halfs per 4 KiB block
         std::memcpy(dst + blk + ((size_t)(ks * 2 + 0) * 64 + lane) * 8 + j, &h, 2);
         std::memcpy(dst + blk + ((size_t)(ks * 2 + 1) * 64 + lane) * 8 + j, &l, 2);
@@ -81,7 +81,7 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // F16S: the same implicit GEMM on v_mfma_f32_32x32x16_f16 with fp32-accurate split operands (three
-// MFMAs per product into an HH and a CROSS accumulator, gen16.hip) -- 16/3 x the f32 matrix rate.
+// MFMAs per product into ONE accumulator: unscaled lo parts, weights * 2^8, g16_common.h) -- 16/3 x the f32 matrix rate.
 // The staged window is then kept as f16 PAIRS of adjacent input channels, P[ci/2][t] (hi image, lo
 // image; time contiguous, same bytes as the f32 window): a B fragment (8 consecutive ci of one time
 // column) is four conflict-free ds_read_b32, and staging stays a 16-byte ds_write per four columns.
@@ -325,8 +325,7 @@ __global__ void __launch_bounds__(64 * WM * WN, F16S ? 2 : 1) conv1d_f32_mfma(Co
   const int LW = BN + (a.K - 1) * a.dil;
   const int total_it = a.nchunks * a.K;
 
-  f32x16 acc[MT][NT];
-  [[maybe_unused]] f32x16 crs[MT][NT];          // F16S: CROSS accumulator (acc is HH)
+  f32x16 acc[MT][NT];                           // F16S: HH, CROSS, CROSS into the one register set (g16_common.h, round 5)
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -334,16 +333,15 @@ __global__ void __launch_bounds__(64 * WM * WN, F16S ? 2 : 1) conv1d_f32_mfma(Co
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         acc[mt][nt][r] = 0.f;
-        if constexpr (F16S) crs[mt][nt][r] = 0.f;
       }
   unsigned* const ph = reinterpret_cast<unsigned*>(xs);          // F16S: hi image [16][LWP] words
   unsigned* const pl = ph + (CONV_CK / 2) * LWP;                 //       lo image
   // hi = the fp32 value truncated to f16 precision (one v_and_b32; packed without rounding by v_cvt_pkrtz, which also
-  // saturates instead of producing inf), lo = the exact fp32 residual * 2^11 (gen16.hip: g16_split2)
+  // saturates instead of producing inf), lo = the exact fp32 residual (g16_common.h: g16_split2)
   auto split_pair = [&](float x0, float x1, unsigned& whi, unsigned& wlo) {
     const float h0 = __uint_as_float(__float_as_uint(x0) & 0xffffe000u), h1 = __uint_as_float(__float_as_uint(x1) & 0xffffe000u);
     whi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h0, h1));
-    wlo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz((x0 - h0) * 2048.f, (x1 - h1) * 2048.f));
+    wlo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0 - h0, x1 - h1));
   };
 
   const float4* wp4 = reinterpret_cast<const float4*>(a.wp);
@@ -455,7 +453,7 @@ __global__ void __launch_bounds__(64 * WM * WN, F16S ? 2 : 1) conv1d_f32_mfma(Co
         asm("v_max_f32 %0, %1, %2" : "=v"(x.x) : "v"(x.x), "v"(y.x));
         asm("v_max_f32 %0, %1, %2" : "=v"(x.y) : "v"(x.y), "v"(y.y));
         const f32x2v hf = {__uint_as_float(__float_as_uint(x.x) & 0xffffe000u), __uint_as_float(__float_as_uint(x.y) & 0xffffe000u)};
-        const f32x2v lf = (x - hf) * 2048.f;          // (packed arithmetic: v_pk_add_f32, v_pk_mul_f32)
+        const f32x2v lf = x - hf;                       // (unscaled: ONE accumulator, g16_common.h)
         wh4[u] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(hf.x, hf.y));
         wl4[u] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lf.x, lf.y));
       }
@@ -610,9 +608,9 @@ __global__ void __launch_bounds__(64 * WM * WN, F16S ? 2 : 1) conv1d_f32_mfma(Co
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = CONV_MFMA16(ah, bh[nt], acc[mt][nt]);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) crs[mt][nt] = CONV_MFMA16(ah, bl[nt], crs[mt][nt]);
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = CONV_MFMA16(ah, bl[nt], acc[mt][nt]);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) crs[mt][nt] = CONV_MFMA16(al, bh[nt], crs[mt][nt]);
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = CONV_MFMA16(al, bh[nt], acc[mt][nt]);
           }
         }
       }
@@ -652,7 +650,7 @@ __global__ void __launch_bounds__(64 * WM * WN, F16S ? 2 : 1) conv1d_f32_mfma(Co
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mt][nt][r] += crs[mt][nt][r] * (1.f / 2048.f);
+        for (int r = 0; r < 16; ++r) acc[mt][nt][r] *= G16_UNSCALE;       // (the weights are packed * G16_WSCALE)
   }
   if constexpr ((CONV_DIAG & 4) != 0) {
     float keep = 0.f;
@@ -965,7 +963,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 1) conv_frame_f16s(ConvArgs a) {
           for (int u = 0; u < 4; ++u) {
             const f32x2v x = {va[q][u], vb[q][u]};
             const f32x2v hf = {__uint_as_float(__float_as_uint(x.x) & 0xffffe000u), __uint_as_float(__float_as_uint(x.y) & 0xffffe000u)};
-            const f32x2v lf = (x - hf) * 2048.f;
+            const f32x2v lf = x - hf;
             wh4[u] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(hf.x, hf.y));
             wl4[u] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lf.x, lf.y));
           }
@@ -983,7 +981,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 1) conv_frame_f16s(ConvArgs a) {
             asm("v_max_f32 %0, %1, %2" : "=v"(x.x) : "v"(x.x), "v"(y.x));
             asm("v_max_f32 %0, %1, %2" : "=v"(x.y) : "v"(x.y), "v"(y.y));
             const f32x2v hf = {__uint_as_float(__float_as_uint(x.x) & 0xffffe000u), __uint_as_float(__float_as_uint(x.y) & 0xffffe000u)};
-            const f32x2v lf = (x - hf) * 2048.f;
+            const f32x2v lf = x - hf;
             wh4[u] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(hf.x, hf.y));
             wl4[u] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lf.x, lf.y));
           }
@@ -998,13 +996,13 @@ __global__ void __launch_bounds__(64 * WM * WN, 1) conv_frame_f16s(ConvArgs a) {
   auto Wn = [&](int j) { return cin(j) * (K * PW); };
   auto Xn = [&](int j) { return cin(j) * NPF; };
 
-  f32x16 acc[MT][NT], crs[MT][NT];
+  f32x16 acc[MT][NT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = crs[mt][nt][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
   {  // the first iteration's windows: behind them, the windows of iterations 1 .. WI - 2
     int n = 0;
@@ -1083,9 +1081,9 @@ __global__ void __launch_bounds__(64 * WM * WN, 1) conv_frame_f16s(ConvArgs a) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = FR_MFMA16(ah, bh[nt], acc[mt][nt]);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) crs[mt][nt] = FR_MFMA16(ah, bl[nt], crs[mt][nt]);
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = FR_MFMA16(ah, bl[nt], acc[mt][nt]);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) crs[mt][nt] = FR_MFMA16(al, bh[nt], crs[mt][nt]);
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = FR_MFMA16(al, bh[nt], acc[mt][nt]);
           }
         }
       }
@@ -1098,7 +1096,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 1) conv_frame_f16s(ConvArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][nt][r] += crs[mt][nt][r] * (1.f / 2048.f);
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] *= G16_UNSCALE;       // (the weights are packed * G16_WSCALE)
   FR_STAMPT(30);
   conv_epi_store<MT, NT>(a, acc, epi, mtile0, n_mtiles, t0, wn, l31, h, b, len);
 #ifdef FR_STAMPS
@@ -1276,7 +1274,7 @@ __global__ void __launch_bounds__(256, 1) conv_frame_splitk(ConvArgs a) {
         asm("v_max_f32 %0, %1, %2" : "=v"(x.x) : "v"(x.x), "v"(y.x));
         asm("v_max_f32 %0, %1, %2" : "=v"(x.y) : "v"(x.y), "v"(y.y));
         const f32x2v hf = {__uint_as_float(__float_as_uint(x.x) & 0xffffe000u), __uint_as_float(__float_as_uint(x.y) & 0xffffe000u)};
-        const f32x2v lf = (x - hf) * 2048.f;
+        const f32x2v lf = x - hf;
         wh4[u] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(hf.x, hf.y));
         wl4[u] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lf.x, lf.y));
       }
@@ -1286,13 +1284,13 @@ __global__ void __launch_bounds__(256, 1) conv_frame_splitk(ConvArgs a) {
     }
   };
 
-  f32x16 acc[MT][NT], crs[MT][NT];
+  f32x16 acc[MT][NT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = crs[mt][nt][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
   // MFMAs of a group from the wave's window slot
   auto compute = [&](const WSet& W, int g, int slot) {
     const unsigned* const ph = reinterpret_cast<const unsigned*>(wbase + (wave * 2 + slot) * WBUF);
@@ -1318,9 +1316,9 @@ __global__ void __launch_bounds__(256, 1) conv_frame_splitk(ConvArgs a) {
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = FR_MFMA16(ah, bh[nt], acc[mt][nt]);
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) crs[mt][nt] = FR_MFMA16(ah, bl[nt], crs[mt][nt]);
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = FR_MFMA16(ah, bl[nt], acc[mt][nt]);
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) crs[mt][nt] = FR_MFMA16(al, bh[nt], crs[mt][nt]);
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = FR_MFMA16(al, bh[nt], acc[mt][nt]);
         }
       }
     }
@@ -1373,7 +1371,7 @@ __global__ void __launch_bounds__(256, 1) conv_frame_splitk(ConvArgs a) {
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        part[(((wave * MT + mt) * NT + nt) * 16 + r) * 64 + lane] = acc[mt][nt][r] + crs[mt][nt][r] * (1.f / 2048.f);
+        part[(((wave * MT + mt) * NT + nt) * 16 + r) * 64 + lane] = acc[mt][nt][r] * G16_UNSCALE;
   __syncthreads();
   auto gather = [&](int mt, int nt, f32x16& v) {
 #pragma unroll
@@ -1412,7 +1410,7 @@ static hipError_t launch_splitk(const ConvArgs& a, int B, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------------------------------
 // conv_t1_gemv: a 1x1 convolution on ONE time step -- the cond_layer(g) / cond(g) projections of the speaker embedding
 // (reference modules.py:153-155, models.py:279, 507): out[b][m] = bias[m] + sum_ci w[m][ci] x[b][ci].  A GEMV: one
-// thread per output row reads its 16-byte pieces of the packed split-f16 image (hi + lo 2^-11 = the fp32 weight to 22
+// thread per output row reads its 16-byte pieces of the packed split-f16 image ((hi + lo) * 2^-8 = the fp32 weight to 22
 // bits, exactly what the MFMA path multiplies) and accumulates in fp32 against the full-precision input.  The matrix
 // kernels spent 38 us on these (a 64-row tile per block for a single column); this is one memory round trip.
 __global__ void __launch_bounds__(256) conv_t1_gemv(ConvArgs a) {
@@ -1436,7 +1434,7 @@ __global__ void __launch_bounds__(256) conv_t1_gemv(ConvArgs a) {
         const int ci0 = chunk * CONV_CK + ks * 16 + hh * 8;
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-          if (ci0 + j < a.Cin) acc = fmaf((float)wh[j] + (float)wl[j] * (1.f / 2048.f), xv[ci0 + j], acc);
+          if (ci0 + j < a.Cin) acc = fmaf(((float)wh[j] + (float)wl[j]) * G16_UNSCALE, xv[ci0 + j], acc);
       }
   }
   a.out[(size_t)b * a.o_bs + (size_t)m * a.o_cs] = acc;
