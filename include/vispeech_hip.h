@@ -28,7 +28,11 @@
 extern "C" {
 #endif
 
-#define VSP_ABI_VERSION 5
+/* 6 (round 5): no entry point changed, but (a) the PACKED WEIGHT ARENA holds the split-f16 convolutions' weights and biases
+ * scaled by 2^8 with unscaled lo parts (one fp32 accumulator per tile) -- an arena packed by an ABI-5 library must not be
+ * adopted (vsp_commit_adopted_weights checks this number in the arena header) -- and (b) vsp_frame_lengths_host no longer
+ * implies a full stream synchronisation after a vsp_encode with given durations (see there). */
+#define VSP_ABI_VERSION 6
 
 enum {
   VSP_OK = 0,

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), s
     assert sorted(_lib.SIGNATURES) == syms, "ctypes signature table and header disagree"
-    assert lib.vsp_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.vsp_abi_version() == _lib.ABI_VERSION == 6
 
 
 @pytest.fixture()

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VSP_LIB_PATH") or os.path.join(_HERE, "lib", "libvispeech_hip.so")
 
 VSP_MAX_LIST = 8
-ABI_VERSION = 5
+ABI_VERSION = 6
 DTYPES = {"float32": 0, "float16": 1, "bfloat16": 2, "float64": 3}   # VSP_DTYPE_*
 PROF_GENERATOR, PROF_ATTENTION, PROF_FRAME = 0, 1, 2
 
