@@ -650,3 +650,18 @@ def test_attention_operands_beyond_the_f16_range_stay_finite(net, dims):
     qkv[0, 2 * H + 1, 11] = 3e5
     out = to_np(net._engine.attention(0, 0, qkv, np.array([T])))
     assert np.isfinite(out).all()
+
+
+def test_weights_beyond_the_packed_f16_range_are_refused(weights):
+    """The split-f16 kernels take their weights * 2^8 as f16 pairs (kernels.h G16_WSCALE): a folded weight of |w| >= ~254
+    cannot be represented and must fail the load loudly instead of turning into inf inside the matrix core."""
+    from vispeech_amd import config as vcfg
+    from vispeech_amd._lib import VspError
+    from vispeech_amd.models import SynthesizerTrn
+    args, kwargs = vcfg.synthesizer_args(vcfg.default_hparams())
+    m = SynthesizerTrn(*args, **kwargs).eval()
+    bad = dict(weights)
+    key = "dec.resblocks.0.convs1.0.weight_g"
+    bad[key] = bad[key] * 1.0e5
+    with pytest.raises(VspError, match="exceeds what the split-f16 matrix path represents"):
+        m.load_state_dict(bad, strict=True)

@@ -351,6 +351,13 @@ struct Filler {
   std::map<std::string, HostTensor> folded;
   bool ok = true;
   std::string missing;
+  float too_large = 0.f;       // a split-f16 weight whose packed form (* G16_WSCALE) leaves the f16 range
+
+  // the split-f16 kernels take their weights * G16_WSCALE as f16 pairs (kernels.h): |w| must stay below 65504 / 256
+  void check_f16_range(const std::vector<float>& dense) {
+    for (float w : dense)
+      if (!(std::fabs(w) * G16_WSCALE < 65000.f)) too_large = std::max(too_large, std::isfinite(w) ? std::fabs(w) : INFINITY);
+  }
 
   const HostTensor* get(const std::string& name) {
     auto it = ctx->raw.find(name);
@@ -391,6 +398,7 @@ struct Filler {
     for (int r = 0; r < c.M; ++r)
       for (int ci = 0; ci < c.Cin; ++ci)
         for (int t = 0; t < c.K; ++t) dense[((size_t)r * c.Cin + ci) * c.K + t] = w(r, ci, t);
+    if (c.f16s) check_f16_range(dense);
     if (c.f16s) pack_conv_weights_f16s(arena.data() + c.w, c.M, c.Cin, c.K, dense.data());
     else pack_conv_weights(arena.data() + c.w, c.M, c.Cin, c.K, dense.data());
     if (c.b >= 0)
@@ -404,6 +412,7 @@ struct Filler {
       for (int co = 0; co < c.Cout; ++co)
         for (int ci = 0; ci < c.Cin; ++ci)
           for (int t = 0; t < c.K; ++t) dense[(((size_t)ph * c.Cout + co) * c.Cin + ci) * c.K + t] = w(ph, co, ci, t);
+    if (ctx->gen_mode != 0) check_f16_range(dense);       // (VSP_GENERATOR=f32 never multiplies this image)
     // [phase][co][ci][tap] is [row = phase * Cout + co][ci][tap]: the stacked-phase form gen16.hip multiplies
     pack_g16_weights(reinterpret_cast<uint16_t*>(arena.data() + c.wg), c.phases * c.Cout, c.Cin, c.K, dense.data());
     for (int co = 0; co < c.Cout; ++co) arena[c.b + co] = b(co) * G16_WSCALE;   // (kernels.h: the bias rides in the scaled accumulator)
@@ -642,6 +651,10 @@ int fill_model(vsp_ctx* ctx, std::vector<float>& arena) {
     for (int c2 = 0; c2 < m.post_c; ++c2)
       for (int j = 0; j < m.post_k; ++j) arena[m.post_wt + (size_t)j * m.post_c + c2] = arena[m.post_w + (size_t)c2 * m.post_k + j];
   if (!f.ok) return ctx->fail(VSP_ERR_STATE, "missing weight: %s", f.missing.c_str());
+  if (f.too_large > 0.f)
+    return ctx->fail(VSP_ERR_UNSUPPORTED, "a convolution weight of magnitude %g (after the weight-norm fold) exceeds what the "
+                                          "split-f16 matrix path represents (|w| < %g); VSP_GENERATOR=f32 / VSP_FRAME=f32 "
+                                          "select the f32 matrix kernels", (double)f.too_large, 65000.0 / G16_WSCALE);
   return VSP_OK;
 }
 
