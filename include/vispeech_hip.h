@@ -116,7 +116,9 @@ int vsp_begin_weights(vsp_ctx* ctx);
 int vsp_missing_weights(const vsp_ctx* ctx);
 /* Size of the packed device arena (depends on the config only). */
 int64_t vsp_weight_arena_bytes(const vsp_ctx* ctx);
-/* Fold + pack (MFMA fragment order) + upload.  dev_arena may be NULL (the library allocates). */
+/* Fold + pack (MFMA fragment order) + upload.  dev_arena may be NULL (the library allocates).  VSP_ERR_STATE while a
+ * required tensor is missing; VSP_ERR_UNSUPPORTED when a folded convolution weight does not fit the packed split-f16 form
+ * (|w| < 253: the images hold w * 2^8 as f16 pairs -- ABI 6). */
 int vsp_finalize_weights(vsp_ctx* ctx, void* dev_arena);
 /* Multi-GPU: a non-root rank adopts an arena that receives rank 0's packed bytes by an RCCL broadcast; no host
  * weights needed.  vsp_adopt_packed_weights only records the pointer (the bytes may still be in flight): the context
