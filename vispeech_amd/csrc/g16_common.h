@@ -104,8 +104,8 @@ __device__ __forceinline__ void g16_for(F&& f) {
 }
 
 // leaky-relu + split of four fp32 values -> hi / lo f16x4.
-// Built from the fewest vector instructions that keep the split exact (round 3: 18 per four values instead of 32; round 5:
-// 14, the lo parts are no longer scaled -- "ONE accumulator per tile" below):
+// Built from the fewest vector instructions that keep the split exact (round 3: 16 per four values + 8 for the leaky-relu
+// instead of 32; round 5: 12 + 8, the lo parts are no longer scaled -- "ONE accumulator per tile" below):
 //   hi = x with the mantissa TRUNCATED to f16 precision: one v_and_b32 on the fp32 bits (0xffffe000); exactly
 //        representable in f16 over the normal range, so v_cvt_pkrtz_f16_f32 packs two of them in ONE instruction
 //        without rounding (and saturates at the largest finite f16 instead of producing inf);
