@@ -206,3 +206,22 @@ def test_c3_batch_trimmed_equals_untrimmed(net, net_untrimmed):
     o0 = run(net_untrimmed, b)[0]
     assert o1.shape == (64, 1, 512 * int(b["frame_lengths"].max()))
     assert torch.equal(o1, o0), float((o1 - o0).abs().max())
+
+
+def test_early_frame_count_copy_changes_nothing_but_the_wait(net, weights, monkeypatch):
+    """With given durations vsp_encode derives the frame counts first and starts their copy to the host;
+    vsp_frame_lengths_host then waits for that copy only (include/vispeech_hip.h).  Same counts, same tensors as the
+    copy-and-synchronise form (VSP_EARLY_FL=0), also when the same context alternates between given and predicted durations."""
+    monkeypatch.setenv("VSP_EARLY_FL", "0")
+    plain = make_net(weights)
+    b = batch_with_frames([70, 33, 51], seed=504)
+    for _ in range(2):
+        o1, m1, (z1, *_), d1, *_ = run(net, b)
+        o0, m0, (z0, *_), d0, *_ = run(plain, b)
+        assert torch.equal(o1, o0) and torch.equal(m1, m0) and torch.equal(z1, z0) and torch.equal(d1, d0)
+        # predicted durations on the same context: the early copy must not be consumed by a call it does not belong to
+        t = lambda a: torch.from_numpy(np.asarray(a)).to(net.device)
+        kw = dict(sid=t(b["sid"]), noise_scale=0.0, pitch_control=t(b["f0"]), energy_control=t(b["energy"]))
+        p1 = net.infer(t(b["phonemes"]), t(b["lengths"]), **kw)
+        p0 = plain.infer(t(b["phonemes"]), t(b["lengths"]), **kw)
+        assert torch.equal(p1[3], p0[3]) and p1[0].shape == p0[0].shape and torch.equal(p1[0], p0[0])
