@@ -231,22 +231,29 @@ struct Run {
   }
 };
 
-// attentions.Encoder.forward (reference attentions.py:35-47).  x_in must already be masked by the
-// caller's semantics (every reference call site passes x * x_mask); it is re-masked on the copy.
-void run_encoder(Run& r, const EncoderW& E, int B, int T, T3 x_in, const int64_t* lengths, T3 y_out) {
+// attentions.Encoder.forward (reference attentions.py:35-47) including the x * x_mask the reference applies at its exit
+// (:46).  x_in must already be masked by the caller's semantics (every reference call site passes x * x_mask); it is
+// read, never written: layer 0 takes it as its input and residual directly (round 5: no entry copy), and the last
+// layer's second LayerNorm writes y_out, masked in place behind it (no exit copy; a mask folded into the LayerNorm
+// kernel's store was measured: its scalar spills made EVERY LayerNorm launch 9 us slower).
+void run_encoder_masked(Run& r, const EncoderW& E, int B, int T, T3 x_in, const int64_t* lengths, T3 y_out) {
   const vsp_config& c = r.ctx->cfg;
   const int h = c.hidden_channels, f = c.filter_channels;
   T3 X = r.ws.t3(B, h, T), S = r.ws.t3(B, h, T), QKV = r.ws.t3(B, 3 * h, T), AT = r.ws.t3(B, h, T),
      FF = r.ws.t3(B, f, T);
   void* AP = r.ctx->att_f16s ? r.ws.bytes(3 * attn_pack_bytes(B, c.n_heads, h / c.n_heads, T)) : nullptr;   // packed q | k | v images
-  // X = x_in * mask  (1x1 identity is not needed: masked copy through the LN-free path)
-  if (!r.dry() && r.ok()) {
-    // masked copy: use the conv-free elementwise path
-    r.chk(launch_copy3(x_in.p, x_in.bs, x_in.cs, X.p, X.bs, X.cs, B, h, T, r.s), "copy");
+  if (E.layers.empty()) {                       // (no layer: y = x * mask)
+    if (!r.dry() && r.ok()) {
+      r.chk(launch_copy3(x_in.p, x_in.bs, x_in.cs, y_out.p, y_out.bs, y_out.cs, B, h, T, r.s), "copy");
+      if (lengths) r.chk(launch_mask3(y_out.p, y_out.bs, y_out.cs, lengths, B, h, T, r.s), "mask");
+    }
+    return;
   }
   for (size_t i = 0; i < E.layers.size(); ++i) {
     const EncLayer& L = E.layers[i];
-    ConvArgs a = r.args(L.qkv, X, QKV, T, T);
+    const T3 Xi = i == 0 ? x_in : X;            // this layer's input
+    const bool last = i + 1 == E.layers.size();
+    ConvArgs a = r.args(L.qkv, Xi, QKV, T, T);
     a.lengths = lengths; a.in_mask = 1;  // x * x_mask feeds the attention (attentions.py:38)
     r.conv(a, B);
     if (!r.dry() && r.ok()) {
@@ -261,9 +268,9 @@ void run_encoder(Run& r, const EncoderW& E, int B, int T, T3 x_in, const int64_t
       if (prof) r.prof_end(VSP_PROF_ATTENTION, (double)B * (4.0 * h * (double)T * T + 4.0 * h * (double)T * (2 * c.window_size + 1)),
                            4.0 * B * 4.0 * h * (double)T, 4.0 * B * 4.0 * h * (double)T);
     }
-    // S = (x*mask for layer 0 | x) + conv_o(att)
+    // S = x + conv_o(att)
     a = r.args(L.o, AT, S, T, T);
-    a.res = X.p; a.r_bs = X.bs; a.r_cs = X.cs;
+    a.res = Xi.p; a.r_bs = Xi.bs; a.r_cs = Xi.cs;
     r.conv(a, B);
     r.ln(S, T3{}, L.g1, L.b1, X, B, h, T);
     // FFN (attentions.py:277-285)
@@ -274,22 +281,15 @@ void run_encoder(Run& r, const EncoderW& E, int B, int T, T3 x_in, const int64_t
     a.lengths = lengths; a.in_mask = 1; a.mask_pre = 1;
     a.res = X.p; a.r_bs = X.bs; a.r_cs = X.cs;
     r.conv(a, B);
-    r.ln(S, T3{}, L.g2, L.b2, X, B, h, T);
+    r.ln(S, T3{}, L.g2, L.b2, last ? y_out : X, B, h, T);
   }
-  // y = x * mask
-  if (!r.dry() && r.ok())
-    r.chk(launch_copy3(X.p, X.bs, X.cs, y_out.p, y_out.bs, y_out.cs, B, h, T, r.s), "copy");
+  // y = x * mask (attentions.py:46)
+  if (lengths && !r.dry() && r.ok()) r.chk(launch_mask3(y_out.p, y_out.bs, y_out.cs, lengths, B, h, T, r.s), "mask");
 }
 
 void mask3(Run& r, T3 x, const int64_t* lengths, int B, int C, int T) {
   if (r.dry() || !r.ok() || !lengths) return;
   r.chk(launch_mask3(x.p, x.bs, x.cs, lengths, B, C, T, r.s), "mask");
-}
-
-// Encoder with the masking the reference applies at entry and exit.
-void run_encoder_masked(Run& r, const EncoderW& E, int B, int T, T3 x_in, const int64_t* lengths, T3 y_out) {
-  run_encoder(r, E, B, T, x_in, lengths, y_out);
-  mask3(r, y_out, lengths, B, r.ctx->cfg.hidden_channels, T);
 }
 
 // modules.WN.forward (reference modules.py:148-176; dilation_rate 1) on H [B][h][T]: H is the running
@@ -1167,8 +1167,7 @@ static int decode_impl(vsp_ctx* ctx, hipStream_t s, Ws& ws, int B, int Tp, int T
   r.conv(a, B);
   if (live) {
     const long n = (long)B * inter * Tf;
-    r.chk(launch_reparam(m_p, logs_p, noise, noise_scale, z_p, n, s), "reparam");
-    r.chk(hipMemcpyAsync(z, z_p, n * sizeof(float), hipMemcpyDeviceToDevice, s), "z copy");
+    r.chk(launch_reparam(m_p, logs_p, noise, noise_scale, z_p, n, s, z), "reparam");   // (z = z_p: the flow transforms z in place)
   }
   run_flow(r, B, Tf, Z, g, frame_lengths);
   const int Tdec = max_len < 0 ? Tf : std::min(Tf, max_len);

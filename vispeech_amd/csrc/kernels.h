@@ -239,7 +239,7 @@ hipError_t launch_length_regulate(const float* x, long x_bs, long x_cs, const in
                                   long o_bs, long o_cs, int B, int C, int Tp, int Tf, hipStream_t s);
 // z_p = m_p + noise * exp(logs_p) * noise_scale ; x_mask[b][t] = t < len[b]
 hipError_t launch_reparam(const float* m_p, const float* logs_p, const float* noise, float noise_scale,
-                          float* z_p, long n, hipStream_t s);
+                          float* z_p, long n, hipStream_t s, float* copy = nullptr);
 // out[i] = standard normal draw first + i of the Philox4x32-10 stream keyed by `seed` (misc.hip)
 hipError_t launch_randn(uint64_t seed, long first, long n, float* out, hipStream_t s);
 hipError_t launch_mask_u8(const int64_t* lengths, uint8_t* mask, int B, int T, hipStream_t s);

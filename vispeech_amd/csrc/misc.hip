@@ -53,7 +53,10 @@ __global__ void __launch_bounds__(256) layernorm_ct(const float* __restrict__ x,
 
 // The same with the column's values held in registers (C <= 4 * NV): ONE read of x (+ res) instead of three, all
 // loads of a thread in flight at once.  Sums run in the same order as above: identical results.
-template <int NV>
+// FULL: C == 4 NV exactly (the 192-channel encoders): no per-channel predicate at all -- with them the kernel kept 48 saved
+// exec masks alive across its four loops (113 spilled scalar registers, 100 exec branches); lanes beyond T read column T - 1
+// and store nothing.
+template <int NV, bool FULL>
 __global__ void __launch_bounds__(256) layernorm_ct_reg(const float* __restrict__ x, long x_bs, long x_cs,
                                                         const float* __restrict__ res, long r_bs, long r_cs,
                                                         const float* __restrict__ gamma,
@@ -63,25 +66,30 @@ __global__ void __launch_bounds__(256) layernorm_ct_reg(const float* __restrict_
   const int tl = threadIdx.x & 63, cg = threadIdx.x >> 6;
   const int b = blockIdx.y, t = blockIdx.x * 64 + tl;
   const bool ok = t < T;
-  const float* xb = x + (size_t)b * x_bs + t;
-  const float* rb = res ? res + (size_t)b * r_bs + t : nullptr;
+  const int tt = ok ? t : T - 1;
+  // (32-bit element offsets within one utterance's tensor: the launcher checks C * stride < 2^31)
+  const int xs = (int)x_cs, rs = (int)r_cs, ys = (int)y_cs;
+  const float* xb = x + (size_t)b * x_bs + tt;
+  const float* rb = res ? res + (size_t)b * r_bs + tt : nullptr;
   float v[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = cg + 4 * i;
-    v[i] = (ok && c < C) ? xb[(size_t)c * x_cs] : 0.f;
+    if constexpr (FULL) v[i] = xb[c * xs];
+    else v[i] = c < C ? xb[c * xs] : 0.f;
   }
   if (rb) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = cg + 4 * i;
-      if (ok && c < C) v[i] += rb[(size_t)c * r_cs];
+      if constexpr (FULL) v[i] += rb[c * rs];
+      else if (c < C) v[i] += rb[c * rs];
     }
   }
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i)
-    if (cg + 4 * i < C) s += v[i];
+    if (FULL || cg + 4 * i < C) s += v[i];
   red[cg][tl] = s;
   __syncthreads();
   const float mean = (red[0][tl] + red[1][tl] + red[2][tl] + red[3][tl]) / (float)C;
@@ -89,7 +97,7 @@ __global__ void __launch_bounds__(256) layernorm_ct_reg(const float* __restrict_
   float v2 = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i)
-    if (cg + 4 * i < C) {
+    if (FULL || cg + 4 * i < C) {
       const float d = v[i] - mean;
       v2 += d * d;
     }
@@ -102,7 +110,7 @@ __global__ void __launch_bounds__(256) layernorm_ct_reg(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = cg + 4 * i;
-      if (c < C) yb[(size_t)c * y_cs] = (v[i] - mean) * rstd * gamma[c] + beta[c];
+      if (FULL || c < C) yb[c * ys] = (v[i] - mean) * rstd * gamma[c] + beta[c];
     }
   }
 }
@@ -110,9 +118,13 @@ __global__ void __launch_bounds__(256) layernorm_ct_reg(const float* __restrict_
 hipError_t launch_layernorm(const float* x, long x_bs, long x_cs, const float* res, long r_bs, long r_cs,
                             const float* gamma, const float* beta, float* y, long y_bs, long y_cs, int B, int C,
                             int T, hipStream_t s) {
-  if (C <= 4 * 48) {
-    hipLaunchKernelGGL(layernorm_ct_reg<48>, dim3(cdiv(T, 64), B), dim3(256), 0, s, x, x_bs, x_cs, res, r_bs, r_cs,
-                       gamma, beta, y, y_bs, y_cs, C, T);
+  if (C <= 4 * 48 && T > 0 && (long)C * x_cs < (1L << 31) && (long)C * y_cs < (1L << 31) && (!res || (long)C * r_cs < (1L << 31))) {
+    if (C == 4 * 48)
+      hipLaunchKernelGGL((layernorm_ct_reg<48, true>), dim3(cdiv(T, 64), B), dim3(256), 0, s, x, x_bs, x_cs, res, r_bs, r_cs,
+                         gamma, beta, y, y_bs, y_cs, C, T);
+    else
+      hipLaunchKernelGGL((layernorm_ct_reg<48, false>), dim3(cdiv(T, 64), B), dim3(256), 0, s, x, x_bs, x_cs, res, r_bs, r_cs,
+                         gamma, beta, y, y_bs, y_cs, C, T);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(layernorm_ct, dim3(cdiv(T, 64), B), dim3(256), 0, s, x, x_bs, x_cs, res, r_bs, r_cs, gamma,
@@ -351,15 +363,18 @@ hipError_t launch_length_regulate(const float* x, long x_bs, long x_cs, const in
 
 // z_p = m_p + noise * exp(logs_p) * noise_scale  (reference models.py:718)
 __global__ void reparam_kernel(const float* __restrict__ m_p, const float* __restrict__ logs_p,
-                               const float* __restrict__ noise, float noise_scale, float* __restrict__ z_p, long n) {
+                               const float* __restrict__ noise, float noise_scale, float* __restrict__ z_p, long n,
+                               float* __restrict__ copy) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float nz = noise ? noise[i] : 0.f;
-  z_p[i] = m_p[i] + nz * expf(logs_p[i]) * noise_scale;
+  const float v = m_p[i] + nz * expf(logs_p[i]) * noise_scale;
+  z_p[i] = v;
+  if (copy) copy[i] = v;        // (the tensor the inverse flow then transforms in place: saves a copy launch)
 }
 hipError_t launch_reparam(const float* m_p, const float* logs_p, const float* noise, float noise_scale, float* z_p,
-                          long n, hipStream_t s) {
-  hipLaunchKernelGGL(reparam_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, m_p, logs_p, noise, noise_scale, z_p, n);
+                          long n, hipStream_t s, float* copy) {
+  hipLaunchKernelGGL(reparam_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, m_p, logs_p, noise, noise_scale, z_p, n, copy);
   return hipGetLastError();
 }
 
