@@ -123,7 +123,11 @@ struct ConvEpi {
 };
 constexpr int CONV_OOR = 0x7ffffff0;
 
-template <int MT, int NT>
+// HOIST (round 5, the latency kernels): one uniform branch per operand kind and m-tile with the element loops inside -- with
+// the branches per ELEMENT conv_frame_f16s spent 3000 of its 10000 instructions in this function, 900 of them reloads of
+// spilled scalar registers (one utterance 3.27 -> 3.17 ms).  The throughput kernel, which comes here once per 32 x 32
+// tile, keeps the per-element form (the hoisted one costs it 0.15 ms on C3).
+template <int MT, int NT, bool HOIST = true>
 __device__ __forceinline__ void conv_epi_load(const ConvArgs& a, ConvEpi<MT, NT>& e, int mtile0, int n_mtiles, int t0, int wn,
                                               int l31, int h, int b, int what = 3) {   // what: 1 = rows, 2 = tiles
   const float* resb = a.res ? a.res + (size_t)b * a.r_bs : nullptr;
@@ -158,22 +162,68 @@ __device__ __forceinline__ void conv_epi_load(const ConvArgs& a, ConvEpi<MT, NT>
     }
     if (!(what & 2)) continue;
     const bool second = a.split_row && mtile * 32 >= a.split_row;
+    if constexpr (!HOIST) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int q = t0 + (wn * NT + nt) * 32 + l31;
-      const bool qin = q < a.Nq && !gate_ep && mtile < n_mtiles;
+      for (int nt = 0; nt < NT; ++nt) {
+        const int q = t0 + (wn * NT + nt) * 32 + l31;
+        const bool qin = q < a.Nq && !gate_ep && mtile < n_mtiles;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = mtile * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-        const bool st = qin && row < a.M;
-        const int oo = st ? (row * (int)a.o_cs + q) * 4 : CONV_OOR;
-        const int oo2 = st ? ((row - a.split_row) * (int)a.o2_cs + q) * 4 : CONV_OOR;
-        // (uniform branches: a launch without a residual / an accumulating destination issues none of these)
-        e.rv[mt][nt][r] = 0u;
-        e.pv[mt][nt][r] = 0u;
-        if (resb && !second) e.rv[mt][nt][r] = __builtin_amdgcn_raw_buffer_load_b32(rr, st ? (row * (int)a.r_cs + q) * 4 : CONV_OOR, 0, 0);
-        if (a.acc_prev && !second) e.pv[mt][nt][r] = __builtin_amdgcn_raw_buffer_load_b32(ro, oo, 0, 0);
-        if (a.acc_prev2 && second) e.pv[mt][nt][r] = __builtin_amdgcn_raw_buffer_load_b32(ro2, oo2, 0, 0);
+        for (int r = 0; r < 16; ++r) {
+          const int row = mtile * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+          const bool st = qin && row < a.M;
+          const int oo = st ? (row * (int)a.o_cs + q) * 4 : CONV_OOR;
+          const int oo2 = st ? ((row - a.split_row) * (int)a.o2_cs + q) * 4 : CONV_OOR;
+          // (uniform branches: a launch without a residual / an accumulating destination issues none of these)
+          e.rv[mt][nt][r] = 0u;
+          e.pv[mt][nt][r] = 0u;
+          if (resb && !second) e.rv[mt][nt][r] = __builtin_amdgcn_raw_buffer_load_b32(rr, st ? (row * (int)a.r_cs + q) * 4 : CONV_OOR, 0, 0);
+          if (a.acc_prev && !second) e.pv[mt][nt][r] = __builtin_amdgcn_raw_buffer_load_b32(ro, oo, 0, 0);
+          if (a.acc_prev2 && second) e.pv[mt][nt][r] = __builtin_amdgcn_raw_buffer_load_b32(ro2, oo2, 0, 0);
+        }
+      }
+      continue;
+    }
+    const bool want_res = resb && !second, want_prev = a.acc_prev && !second, want_prev2 = a.acc_prev2 && second;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { e.rv[mt][nt][r] = 0u; e.pv[mt][nt][r] = 0u; }
+    if (!(want_res || want_prev || want_prev2)) continue;
+    const bool tile_in = !gate_ep && mtile < n_mtiles;
+    if (want_res) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int q = t0 + (wn * NT + nt) * 32 + l31;
+        const bool qin = q < a.Nq && tile_in;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = mtile * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+          e.rv[mt][nt][r] = __builtin_amdgcn_raw_buffer_load_b32(rr, (qin && row < a.M) ? (row * (int)a.r_cs + q) * 4 : CONV_OOR, 0, 0);
+        }
+      }
+    }
+    if (want_prev) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int q = t0 + (wn * NT + nt) * 32 + l31;
+        const bool qin = q < a.Nq && tile_in;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = mtile * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+          e.pv[mt][nt][r] = __builtin_amdgcn_raw_buffer_load_b32(ro, (qin && row < a.M) ? (row * (int)a.o_cs + q) * 4 : CONV_OOR, 0, 0);
+        }
+      }
+    }
+    if (want_prev2) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int q = t0 + (wn * NT + nt) * 32 + l31;
+        const bool qin = q < a.Nq && tile_in;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = mtile * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+          e.pv[mt][nt][r] = __builtin_amdgcn_raw_buffer_load_b32(ro2, (qin && row < a.M) ? ((row - a.split_row) * (int)a.o2_cs + q) * 4 : CONV_OOR, 0, 0);
+        }
       }
     }
   }
@@ -190,12 +240,31 @@ __device__ __forceinline__ void conv_div(float& v, float div) {
   }
 }
 
+// (round 5: every optional step is ONE uniform branch around a 16-element loop, and full m-tiles address their rows through
+// the buffer instruction's SCALAR offset -- written per element, with a multiply per address, the epilogue was ~200
+// instructions per value in every frame-rate kernel.  Same operations in the same order per element: identical results.)
 template <int MT, int NT>
 __device__ __forceinline__ void conv_epi_store(const ConvArgs& a, f32x16 (&acc)[MT][NT], const ConvEpi<MT, NT>& e, int mtile0,
                                                int n_mtiles, int t0, int wn, int l31, int h, int b, int len) {
   float* outb = a.out + (size_t)b * a.o_bs;
   const bool has_cond = a.cond != nullptr, has_res = a.res != nullptr;
   const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(outb, 0, CONV_OOR, 0x00020000);
+  const int ocs4 = (int)a.o_cs * 4;
+  // the 16 rows of a lane in tile rows [r0, r0 + 32): r0 + 4 h + 8 g + i -- full tiles: one vector offset + scalar row offsets
+  auto store_tile = [&](const __amdgpu_buffer_rsrc_t& rs, const float (&v)[16], int row_first, int rows_end, int cs4, int q, bool qin) {
+    if (row_first + 32 <= rows_end) {
+      const int vo = qin ? (row_first + 4 * h) * cs4 + q * 4 : CONV_OOR;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), rs, vo, (8 * (r >> 2) + (r & 3)) * cs4, 0);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row_first + 8 * (r >> 2) + 4 * h + (r & 3);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), rs, (qin && row < rows_end) ? row * cs4 + q * 4 : CONV_OOR, 0, 0);
+      }
+    }
+  };
   if (a.act == 2) {
     // WN gate (reference commons.py:100-107): tiles (2i, 2i+1) hold the tanh / sigmoid halves.
     if constexpr (MT % 2 == 0) {
@@ -207,17 +276,25 @@ __device__ __forceinline__ void conv_epi_store(const ConvArgs& a, f32x16 (&acc)[
         for (int nt = 0; nt < NT; ++nt) {
           const int q = t0 + (wn * NT + nt) * 32 + l31;
           const bool qin = q < a.Nq, valid = q < len;
+          float va[16], vb[16], v[16];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int g = r >> 2, i = r & 3;
-            float va = acc[2 * mp][nt][r], vb = acc[2 * mp + 1][nt][r];
-            if (a.bias) { va += e.bv[2 * mp][r]; vb += e.bv[2 * mp + 1][r]; }
-            if (has_cond) { va += e.cv[2 * mp][r]; vb += e.cv[2 * mp + 1][r]; }
-            float v = tanhf(va) * (1.f / (1.f + expf(-vb)));
-            if (a.mask_post && !valid) v = 0.f;
-            const int orow = (mtile >> 1) * 32 + 8 * g + 4 * h + i;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro, qin ? (orow * (int)a.o_cs + q) * 4 : CONV_OOR, 0, 0);
+          for (int r = 0; r < 16; ++r) { va[r] = acc[2 * mp][nt][r]; vb[r] = acc[2 * mp + 1][nt][r]; }
+          if (a.bias) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { va[r] += e.bv[2 * mp][r]; vb[r] += e.bv[2 * mp + 1][r]; }
           }
+          if (has_cond) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { va[r] += e.cv[2 * mp][r]; vb[r] += e.cv[2 * mp + 1][r]; }
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = tanhf(va[r]) * (1.f / (1.f + expf(-vb[r])));
+          if (a.mask_post && !valid) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = 0.f;
+          }
+          // (output rows (mtile >> 1) * 32 + ..: every gated row exists -- the launcher requires Cout % 64 == 0)
+          store_tile(ro, v, (mtile >> 1) * 32, (mtile >> 1) * 32 + 32, ocs4, q, qin);
         }
       }
     }
@@ -229,46 +306,214 @@ __device__ __forceinline__ void conv_epi_store(const ConvArgs& a, f32x16 (&acc)[
   for (int mt = 0; mt < MT; ++mt) {
     const int mtile = mtile0 + mt;
     if (mtile >= n_mtiles) continue;
-    if (a.split_row && mtile * 32 >= a.split_row) {
-      // second destination: out2[row - split_row] = conv + bias (+ out2)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int q = t0 + (wn * NT + nt) * 32 + l31;
-        const bool qin = q < a.Nq, keep = !a.mask_post2 || q < len;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = mtile * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-          float v = acc[mt][nt][r];
-          if (a.bias) v += e.bv[mt][r];
-          if (a.acc_prev2) v += __uint_as_float(e.pv[mt][nt][r]);
-          if (!keep) v = 0.f;
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro2,
-                                                (qin && row < a.M) ? ((row - a.split_row) * (int)a.o2_cs + q) * 4 : CONV_OOR, 0, 0);
-        }
-      }
-      continue;
-    }
+    const bool second = a.split_row && mtile * 32 >= a.split_row;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int q = t0 + (wn * NT + nt) * 32 + l31;
       const bool qin = q < a.Nq, valid = q < len;
+      float v[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = mtile * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-        float v = acc[mt][nt][r];
-        if (a.bias) v += e.bv[mt][r];
-        if (has_cond) v += e.cv[mt][r];
-        if (a.act == 1) v = fmaxf(v, 0.f);
-        if (a.mask_pre && !valid) v = 0.f;
-        if (a.alpha != 1.f) v *= a.alpha;
-        if (has_res) v += __uint_as_float(e.rv[mt][nt][r]);
-        if (a.acc_prev) v += __uint_as_float(e.pv[mt][nt][r]);
-        conv_div(v, a.div);
-        if (a.mask_post && !valid) v = 0.f;
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro, (qin && row < a.M) ? (row * (int)a.o_cs + q) * 4 : CONV_OOR, 0, 0);
+      for (int r = 0; r < 16; ++r) v[r] = acc[mt][nt][r];
+      if (a.bias) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += e.bv[mt][r];
       }
+      if (second) {
+        // second destination: out2[row - split_row] = conv + bias (+ out2)
+        if (a.acc_prev2) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] += __uint_as_float(e.pv[mt][nt][r]);
+        }
+        if (a.mask_post2 && !valid) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = 0.f;
+        }
+        store_tile(ro2, v, mtile * 32 - a.split_row, a.M - a.split_row, (int)a.o2_cs * 4, q, qin);
+        continue;
+      }
+      if (has_cond) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += e.cv[mt][r];
+      }
+      if (a.act == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (a.mask_pre && !valid) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = 0.f;
+      }
+      if (a.alpha != 1.f) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] *= a.alpha;
+      }
+      if (has_res) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += __uint_as_float(e.rv[mt][nt][r]);
+      }
+      if (a.acc_prev) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += __uint_as_float(e.pv[mt][nt][r]);
+      }
+      if (a.div != 1.f) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { asm volatile("" : "+v"(v[r])); v[r] /= a.div; }
+      }
+      if (a.mask_post && !valid) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = 0.f;
+      }
+      store_tile(ro, v, mtile * 32, a.M, ocs4, q, qin);
     }
   }
+}
+
+// LEAN epilogue of ONE 32 x 32 tile of the throughput kernel (round 5).  conv_epi_load / conv_epi_store evaluate every
+// optional step of the epilogue per ELEMENT and compute every address with a multiply: ~200 instructions per value and
+// 1500 reloads of spilled scalar registers in conv1d_f32_mfma<2,1,1,4> (9700 vector instructions around 24 MFMAs).  Here
+// the lane's address is computed once (the row offsets are uniform: they ride in the buffer instruction's scalar offset),
+// and every optional step is ONE uniform branch around a 16-element loop.  Same operations in the same order per
+// element as conv_epi_store's plain path: identical results.  Tiles that need the gate, the second destination or a
+// partial last m-tile keep the general path.
+__device__ __forceinline__ bool conv_tile_lean_ok(const ConvArgs& a, int mtile) {
+  return a.act != 2 && (a.split_row & 31) == 0 && mtile * 32 + 32 <= a.M && (a.M & 3) == 0 &&
+         (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0) &&
+         (!a.cond || ((reinterpret_cast<uintptr_t>(a.cond) & 15) == 0 && (a.cond_bs & 3) == 0));
+}
+__device__ __forceinline__ void conv_tile_lean(const ConvArgs& a, f32x16& acc, int mtile, int tq, int l31, int h, int b, int len) {
+  const int q = tq + l31;
+  const bool qin = q < a.Nq, valid = q < len;
+  const int row0 = mtile * 32 + 4 * h;                       // the lane's rows: row0 + 8 g + i
+  float* outb = a.out + (size_t)b * a.o_bs;
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(outb, 0, CONV_OOR, 0x00020000);
+  const int ocs4 = (int)a.o_cs * 4;
+  const int vo = qin ? (row0 * (int)a.o_cs + q) * 4 : CONV_OOR;   // + (8 g + i) o_cs 4 as the SCALAR offset of the instruction
+  float v[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = acc[r];
+  if (a.bias) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 t = *reinterpret_cast<const float4*>(a.bias + row0 + 8 * g);
+      v[4 * g] += t.x; v[4 * g + 1] += t.y; v[4 * g + 2] += t.z; v[4 * g + 3] += t.w;
+    }
+  }
+  if (a.split_row && mtile * 32 >= a.split_row) {
+    // second destination (conv_epi_store): out2[row - split_row] = conv + bias (+ out2), masked by mask_post2
+    const __amdgpu_buffer_rsrc_t ro2 = __builtin_amdgcn_make_buffer_rsrc(a.out2 + (size_t)b * a.o2_bs, 0, CONV_OOR, 0x00020000);
+    const int o2cs4 = (int)a.o2_cs * 4;
+    const int vo2 = qin ? ((row0 - a.split_row) * (int)a.o2_cs + q) * 4 : CONV_OOR;
+    if (a.acc_prev2) {
+      unsigned pv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pv[r] = __builtin_amdgcn_raw_buffer_load_b32(ro2, vo2, (8 * (r >> 2) + (r & 3)) * o2cs4, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] += __uint_as_float(pv[r]);
+    }
+    if (a.mask_post2 && !valid) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), ro2, vo2, (8 * (r >> 2) + (r & 3)) * o2cs4, 0);
+    return;
+  }
+  if (a.cond) {
+    const float* condb = a.cond + (size_t)b * a.cond_bs;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 t = *reinterpret_cast<const float4*>(condb + row0 + 8 * g);
+      v[4 * g] += t.x; v[4 * g + 1] += t.y; v[4 * g + 2] += t.z; v[4 * g + 3] += t.w;
+    }
+  }
+  if (a.act == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+  }
+  if (a.mask_pre && !valid) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = 0.f;
+  }
+  if (a.alpha != 1.f) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] *= a.alpha;
+  }
+  if (a.res) {
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res + (size_t)b * a.r_bs), 0, CONV_OOR, 0x00020000);
+    const int rcs4 = (int)a.r_cs * 4;
+    const int vr = qin ? (row0 * (int)a.r_cs + q) * 4 : CONV_OOR;
+    unsigned rv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rv[r] = __builtin_amdgcn_raw_buffer_load_b32(rr, vr, (8 * (r >> 2) + (r & 3)) * rcs4, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] += __uint_as_float(rv[r]);
+  }
+  if (a.acc_prev) {
+    unsigned pv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pv[r] = __builtin_amdgcn_raw_buffer_load_b32(ro, vo, (8 * (r >> 2) + (r & 3)) * ocs4, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] += __uint_as_float(pv[r]);
+  }
+  if (a.div != 1.f) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { asm volatile("" : "+v"(v[r])); v[r] /= a.div; }
+  }
+  if (a.mask_post && !valid) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = 0.f;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), ro, vo, (8 * (r >> 2) + (r & 3)) * ocs4, 0);
+}
+
+// ... and of one tanh / sigmoid tile PAIR of the WN gate (reference commons.py:100-107; conv_epi_store's gate path)
+__device__ __forceinline__ bool conv_gate_lean_ok(const ConvArgs& a, int mtile, int n_mtiles) {
+  return a.act == 2 && mtile + 1 < n_mtiles && (a.M & 3) == 0 && mtile * 32 + 64 <= a.M &&
+         (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0) &&
+         (!a.cond || ((reinterpret_cast<uintptr_t>(a.cond) & 15) == 0 && (a.cond_bs & 3) == 0));
+}
+__device__ __forceinline__ void conv_gate_lean(const ConvArgs& a, f32x16& acc_t, f32x16& acc_s, int mtile, int tq, int l31, int h, int b,
+                                               int len) {
+  const int q = tq + l31;
+  const bool qin = q < a.Nq, valid = q < len;
+  const int row0 = mtile * 32 + 4 * h;                       // tanh rows row0 + 8 g + i, sigmoid rows 32 further
+  float* outb = a.out + (size_t)b * a.o_bs;
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(outb, 0, CONV_OOR, 0x00020000);
+  const int ocs4 = (int)a.o_cs * 4;
+  const int vo = qin ? (((mtile >> 1) * 32 + 4 * h) * (int)a.o_cs + q) * 4 : CONV_OOR;
+  float va[16], vb[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { va[r] = acc_t[r]; vb[r] = acc_s[r]; }
+  if (a.bias) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 t = *reinterpret_cast<const float4*>(a.bias + row0 + 8 * g), u = *reinterpret_cast<const float4*>(a.bias + row0 + 32 + 8 * g);
+      va[4 * g] += t.x; va[4 * g + 1] += t.y; va[4 * g + 2] += t.z; va[4 * g + 3] += t.w;
+      vb[4 * g] += u.x; vb[4 * g + 1] += u.y; vb[4 * g + 2] += u.z; vb[4 * g + 3] += u.w;
+    }
+  }
+  if (a.cond) {
+    const float* condb = a.cond + (size_t)b * a.cond_bs;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 t = *reinterpret_cast<const float4*>(condb + row0 + 8 * g), u = *reinterpret_cast<const float4*>(condb + row0 + 32 + 8 * g);
+      va[4 * g] += t.x; va[4 * g + 1] += t.y; va[4 * g + 2] += t.z; va[4 * g + 3] += t.w;
+      vb[4 * g] += u.x; vb[4 * g + 1] += u.y; vb[4 * g + 2] += u.z; vb[4 * g + 3] += u.w;
+    }
+  }
+  float v[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = tanhf(va[r]) * (1.f / (1.f + expf(-vb[r])));
+  if (a.mask_post && !valid) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = 0.f;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), ro, vo, (8 * (r >> 2) + (r & 3)) * ocs4, 0);
 }
 
 // (the throughput kernel, at two blocks per CU: one tile -- for the gate, one pair of tiles -- at a time)
@@ -279,12 +524,25 @@ __device__ __forceinline__ void conv_store_slices(const ConvArgs& a, f32x16 (&ac
   for (int ms = 0; ms < MT / S; ++ms)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
+      const int tq = t0 + (wn * NT + nt) * 32;
+      if constexpr (S == 1) {
+        const int mtile = mtile0 + ms;
+        if (mtile < n_mtiles && conv_tile_lean_ok(a, mtile)) {      // (uniform)
+          conv_tile_lean(a, acc[ms][nt], mtile, tq, l31, h, b, len);
+          continue;
+        }
+      } else if constexpr (S == 2) {
+        const int mtile = mtile0 + 2 * ms;
+        if (conv_gate_lean_ok(a, mtile, n_mtiles)) {                 // (uniform)
+          conv_gate_lean(a, acc[2 * ms][nt], acc[2 * ms + 1][nt], mtile, tq, l31, h, b, len);
+          continue;
+        }
+      }
       f32x16 t[S][1];
 #pragma unroll
       for (int u = 0; u < S; ++u) t[u][0] = acc[S * ms + u][nt];
       ConvEpi<S, 1> e;
-      const int tq = t0 + (wn * NT + nt) * 32;
-      conv_epi_load<S, 1>(a, e, mtile0 + S * ms, n_mtiles, tq, 0, l31, h, b);
+      conv_epi_load<S, 1, false>(a, e, mtile0 + S * ms, n_mtiles, tq, 0, l31, h, b);
       conv_epi_store<S, 1>(a, t, e, mtile0 + S * ms, n_mtiles, tq, 0, l31, h, b, len);
     }
 }
