@@ -556,9 +556,13 @@ __device__ __forceinline__ void conv_store_plain(const ConvArgs& a, f32x16 (&acc
   }
 }
 
-template <int MT, int NT, int WM, int WN, bool F16S, bool RING = false>
+// PRUNE (round 5): the instantiation for what the frame-rate path launches almost always -- split-f16, weight ring, the
+// prefetched window path, no transposed-convolution epilogue -- WITHOUT the code of the four other window stagings and of
+// the polyphase epilogue: the launcher checks what those branches test at run time.
+template <int MT, int NT, int WM, int WN, bool F16S, bool RING = false, bool PRUNE = false>
 __global__ void __launch_bounds__(64 * WM * WN, F16S ? 2 : 1) conv1d_f32_mfma(ConvArgs a) {
   static_assert(!RING || F16S, "the weight ring serves the split-f16 path");
+  static_assert(!PRUNE || (F16S && RING), "the pruned form is the split-f16 ring kernel");
   constexpr int BN = 32 * NT * WN;
   constexpr int LWP = BN + CONV_HALO;
   constexpr int NW = WM * WN;
@@ -720,13 +724,15 @@ __global__ void __launch_bounds__(64 * WM * WN, F16S ? 2 : 1) conv1d_f32_mfma(Co
       *reinterpret_cast<u32x4*>(pl + o) = u32x4{wl4[0], wl4[1], wl4[2], wl4[3]};
     }
   };
-  const bool pref = PREF && vec && (CONV_DIAG & 2) == 0 && slope_eff >= 0.f && slope_eff <= 1.f;
+  static_assert(!PRUNE || PREF, "the pruned form stages its window through the prefetch path");
+  const bool pref = PRUNE || (PREF && vec && (CONV_DIAG & 2) == 0 && slope_eff >= 0.f && slope_eff <= 1.f);
   if constexpr (PREF) { if (pref) st_load(0); }
   int it = 0;
   for (int chunk = 0; chunk < a.nchunks; ++chunk) {
     // ---- stage x[chunk] -> LDS with the prologue applied
     if (pref) {
       if constexpr (PREF) st_write(chunk);      // (the compiler waits for the window here: a chunk after its request)
+    } else if constexpr (PRUNE) {
     } else if (vec && F16S) {
       // pairs of adjacent input channels: two 16-byte loads -> one 16-byte LDS store per image
       constexpr int RWP = (CONV_CK / 2) / NW;
@@ -923,7 +929,7 @@ __global__ void __launch_bounds__(64 * WM * WN, F16S ? 2 : 1) conv1d_f32_mfma(Co
   const float* resb = a.res ? a.res + (size_t)b * a.r_bs : nullptr;
   float* outb = a.out + (size_t)b * a.o_bs;
   const float* condb = a.cond ? a.cond + (size_t)b * a.cond_bs : nullptr;
-  if (a.ups_s == 0) {
+  if (PRUNE || a.ups_s == 0) {
     conv_store_plain<MT, NT>(a, acc, mtile0, n_mtiles, t0, wn, l31, h, b, len);
     return;
   }
@@ -1402,14 +1408,14 @@ static bool launch_frame_k(const ConvArgs& a, int B, hipStream_t s, hipError_t& 
   }
 }
 
-template <int MT, int NT, int WM, int WN, bool F16S = false, bool RING = false>
+template <int MT, int NT, int WM, int WN, bool F16S = false, bool RING = false, bool PRUNE = false>
 static hipError_t launch_tile(const ConvArgs& a, int B, hipStream_t s) {
   constexpr int BN = 32 * NT * WN, BM = 32 * MT * WM;
   constexpr size_t lds = (size_t)CONV_CK * (BN + CONV_HALO) * sizeof(float) +
                          (RING ? (size_t)conv_ring_slots(MT, WM) * MT * WM * 4096 : 0);
   static_assert(lds <= 160 * 1024, "LDS budget (<= 80 KiB: two blocks per CU)");
   static std::atomic<uint64_t> attr_done{0};
-  auto kern = conv1d_f32_mfma<MT, NT, WM, WN, F16S, RING>;
+  auto kern = conv1d_f32_mfma<MT, NT, WM, WN, F16S, RING, PRUNE>;
   if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, attr_done); e != hipSuccess) return e;
   dim3 grid((a.Nq + BN - 1) / BN, (a.M + BM - 1) / BM, B);
   hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, a);
@@ -1799,6 +1805,10 @@ hipError_t launch_conv(const ConvArgs& a, int B, hipStream_t s) {
     const bool wide = force_rows ? force_rows == 128 : a.Nq >= 1024;
     if (a.M <= 64 || (a.M % 128 != 0 && a.M < 256) || !wide) {
       if (a.Nq >= 1024) return launch_tile<2, 2, 1, 4, true, true>(a, B, s);
+      // (what conv1d_f32_mfma's pruned form assumes: 16-byte aligned rows, a leaky-relu slope the max form covers)
+      const bool vec_ok = ((a.x_cs & 3) == 0) && ((a.x_bs & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
+      const float sl_eff = a.in_act ? a.in_slope : 1.f;
+      if (vec_ok && sl_eff >= 0.f && sl_eff <= 1.f && a.ups_s == 0 && !(CONV_DIAG & 2)) return launch_tile<2, 1, 1, 4, true, true, true>(a, B, s);
       return launch_tile<2, 1, 1, 4, true, true>(a, B, s);
     }
     return launch_tile<2, 2, 2, 2, true, true>(a, B, s);
