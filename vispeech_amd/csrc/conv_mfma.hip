@@ -1803,14 +1803,16 @@ hipError_t launch_conv(const ConvArgs& a, int B, hipStream_t s) {
     constexpr int force_rows = 0;
 #endif
     const bool wide = force_rows ? force_rows == 128 : a.Nq >= 1024;
+    // (what conv1d_f32_mfma's pruned form assumes: 16-byte aligned rows, a leaky-relu slope the max form covers, no polyphase)
+    const bool vec_ok = ((a.x_cs & 3) == 0) && ((a.x_bs & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
+    const float sl_eff = a.in_act ? a.in_slope : 1.f;
+    const bool prune_ok = vec_ok && sl_eff >= 0.f && sl_eff <= 1.f && a.ups_s == 0 && !(CONV_DIAG & 2);
     if (a.M <= 64 || (a.M % 128 != 0 && a.M < 256) || !wide) {
       if (a.Nq >= 1024) return launch_tile<2, 2, 1, 4, true, true>(a, B, s);
-      // (what conv1d_f32_mfma's pruned form assumes: 16-byte aligned rows, a leaky-relu slope the max form covers)
-      const bool vec_ok = ((a.x_cs & 3) == 0) && ((a.x_bs & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
-      const float sl_eff = a.in_act ? a.in_slope : 1.f;
-      if (vec_ok && sl_eff >= 0.f && sl_eff <= 1.f && a.ups_s == 0 && !(CONV_DIAG & 2)) return launch_tile<2, 1, 1, 4, true, true, true>(a, B, s);
+      if (prune_ok) return launch_tile<2, 1, 1, 4, true, true, true>(a, B, s);
       return launch_tile<2, 1, 1, 4, true, true>(a, B, s);
     }
+    if (prune_ok) return launch_tile<2, 2, 2, 2, true, true, true>(a, B, s);
     return launch_tile<2, 2, 2, 2, true, true>(a, B, s);
   }
   if (a.f16s) {
