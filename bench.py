@@ -73,6 +73,9 @@ def parse(argv=None):
                    help="one GPU, no process group: synthesise ONLY rank --shard-rank's shard_range slice of the batch under the "
                         "GLOBAL frame padding -- the per-GPU operating point a --gpus N run lands on (profiles/r05_per_rank_*)")
     p.add_argument("--shard-rank", type=int, default=0)
+    p.add_argument("--dump-wave", default=None,
+                   help="test hook: rank 0 writes the waveform batch of one more (untimed) step -- gathered over the ranks when "
+                        "there is a process group -- to this .npy file")
     p.add_argument("--dist", action="store_true",
                    help="initialise torch.distributed (RCCL) even at --gpus 1: the weight broadcast, the frame-count "
                         "all-reduce and the waveform gather run through the collectives with one rank")
@@ -217,7 +220,15 @@ def main():
     # down with it): after VSP_BENCH_DUMP_AFTER seconds (default 900) every thread's Python stack goes to stderr and the
     # process exits -- a hung collective never outlives the run, and the dump says where it hung
     import faulthandler
-    faulthandler.dump_traceback_later(int(os.environ.get("VSP_BENCH_DUMP_AFTER", "900")), exit=True)
+    dump_after = int(os.environ.get("VSP_BENCH_DUMP_AFTER", "900"))
+
+    def arm(extra: float = 0.0):
+        """(Re)start the hang watchdog for the next PHASE: it is a hang detector, not a deadline for the whole run -- every
+        phase gets its own window (a healthy long run, --steps 10000 or a slow CPU baseline, must not be killed)."""
+        faulthandler.cancel_dump_traceback_later()
+        faulthandler.dump_traceback_later(dump_after + int(extra), exit=True)
+
+    arm()
     import numpy as np
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -299,6 +310,11 @@ def main():
     if args.shard_of:
         tf_global = int(batch["frame_lengths"].max())          # what the all-reduce MAX of the N ranks would return
     valid_samples = 512 * int(frames_local.sum())
+    # frames the generator computes on this rank (trimmed tails: an utterance runs to length + back + 1 + fwd frames, the
+    # rest of its padded waveform is filled from the steady state) -- the work the roofline figures are charged for
+    back_f, fwd_f = eng.generator_frame_dependence()
+    trim_on = os.environ.get("VSP_TRIM_TAILS", "1") != "0" and os.environ.get("VSP_GENERATOR", "f16s") != "f32"
+    frames_computed = int(np.minimum(frames_local + back_f + 1 + fwd_f, tf_global).sum()) if trim_on else int(B * tf_global)
     r = np.random.Generator(np.random.PCG64(wl["seed"] * 7919 + 13))
     noise_np = np.zeros((B_all if sharded_global else B, dims.inter_channels, tf_global), dtype=np.float32)
     if "duration_control" in ctl:
@@ -330,15 +346,21 @@ def main():
         if use_dist:
             dist.barrier()
 
+    arm()
+    t_w0 = time.perf_counter()
     for _ in range(args.warmup):
         step()
     eng.profile(False)
     drain()
+    # the timed phase's window scales with its length: the warm-up's own per-step time x steps, with a wide margin
+    per_step_guess = (time.perf_counter() - t_w0) / max(args.warmup, 1)
+    arm(extra=4.0 * per_step_guess * args.steps)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     drain()
     dt = time.perf_counter() - t0
+    arm(extra=4.0 * per_step_guess * args.steps)
     dt_rank = dt
     # the gather's share of a step: the same K steps once more WITHOUT the exchange (untimed for `value`)
     dt_nogather = None
@@ -354,36 +376,61 @@ def main():
     # ---- second, untimed pass: HIP events around every launch of the profiled classes (rank 0's numbers are reported)
     prof = {}
     if args.profile_steps > 0:
+        arm()
         eng.profile(True)
         for _ in range(args.profile_steps):
             step()
         drain()
         fams = eng.profile_read_families(_lib.PROF_GENERATOR)
         for name, cls in (("generator", _lib.PROF_GENERATOR), ("attention", _lib.PROF_ATTENTION), ("frame", _lib.PROF_FRAME)):
-            n, ms, fl, by, bx = eng.profile_read(reset=True, cls=cls)
+            n, ms, fl, by, bx, bm = eng.profile_read(reset=True, cls=cls)
             prof[name] = dict(launches=n // args.profile_steps, ms=ms / args.profile_steps, flops=fl / args.profile_steps,
-                              bytes=by / args.profile_steps, bytes_ext=bx / args.profile_steps)
+                              bytes=by / args.profile_steps, bytes_ext=bx / args.profile_steps, moved=bm / args.profile_steps)
         if fams:
             # the kernel family with the largest share of the step (HIP events around each of its launches): what a reader
             # recomputes from profiles/*kernel_stats.csv (name, launches per step, average duration)
             KN = {("pair", 128): "g16_pp (ResBlock conv pairs, 128 channels)", ("pair", 64): "g16_pair<2,2,3,8,2> (ResBlock conv pairs, 64 channels)",
                   ("pair", 32): "g16_rw (ResBlock conv pairs, 32 channels, weights in registers)",
-                  ("chain", 32): "g16_rc (whole k3 ResBlock, 32 channels)", ("conv", 256): "g16_conv / g16_convp (256-channel ResBlock convolutions)",
+                  ("chain", 32): "g16_rc (whole k3 ResBlock, 32 channels)", ("conv", 256): "g16_conv (256-channel ResBlock convolutions; g16_convp on uniform batches)",
                   ("conv", 128): "g16_conv (128-channel k11 ResBlock convolutions)"}
             f = fams[0]
             k = args.profile_steps
             avg = f["ms"] / max(f["launches"], 1)
             prof["dominant"] = {
-                "name": KN.get((f["kind"], f["channels"]), f"{f['kind']} C={f['channels']}"),
+                "name": KN.get((f["kind"], f["channels"]), f"{f['kind']} C={f['channels']}"), "family": f"{f['kind']}{f['channels']}",
                 "launches": f["launches"] // k, "avg_launch_ms": avg, "ms_per_step": f["ms"] / k,
                 "alg_flops_per_launch": f["flops"] / max(f["launches"], 1), "alg_bytes_per_launch": f["bytes"] / max(f["launches"], 1),
                 "alg_tflops": f["flops"] / max(f["ms"], 1e-9) / 1e9, "alg_gbs": f["bytes"] / max(f["ms"], 1e-9) / 1e6,
                 "alg_frac_mfma": f["flops"] / max(f["ms"], 1e-9) / 1e9 / PEAK_F16_MFMA_TFLOPS,
                 "alg_frac_hbm": f["bytes"] / max(f["ms"], 1e-9) / 1e6 / PEAK_HBM_GBS,
-                "families_ms_per_step": {f"{x['kind']}{x['channels']}": round(x["ms"] / k, 3) for x in fams}}
+                # what the launch must move through HBM AS FUSED (input, output, residual, previous sum once each): the
+                # byte figure that bounds a fused launch -- SURVEY 8d's layer-boundary model above charges a fused pair
+                # the four passes of the two convolutions it replaces and is the contract's algorithmic figure only
+                "moved_bytes_per_launch": f["moved"] / max(f["launches"], 1),
+                "moved_gbs": f["moved"] / max(f["ms"], 1e-9) / 1e6,
+                "moved_frac_hbm": f["moved"] / max(f["ms"], 1e-9) / 1e6 / PEAK_HBM_GBS,
+                "mfma_issue_frac": 3.0 * f["flops"] / max(f["ms"], 1e-9) / 1e9 / PEAK_F16_MFMA_TFLOPS,
+                "families_ms_per_step": {f"{x['kind']}{x['channels']}": round(x["ms"] / k, 3) for x in fams},
+                "families": {f"{x['kind']}{x['channels']}": {
+                    "launches": x["launches"] // k, "avg_launch_ms": round(x["ms"] / max(x["launches"], 1), 4),
+                    "alg_gbs": round(x["bytes"] / max(x["ms"], 1e-9) / 1e6, 1),
+                    "moved_gbs": round(x["moved"] / max(x["ms"], 1e-9) / 1e6, 1),
+                    "alg_tflops": round(x["flops"] / max(x["ms"], 1e-9) / 1e9, 1)} for x in fams}}
         eng.profile(False)
         if use_dist:
             dist.barrier()
+
+    if args.dump_wave:
+        # one more untimed step on every rank; rank 0 keeps what the exchange delivered (the test compares an N-rank RCCL
+        # run with the one-GPU run of the same batch)
+        arm()
+        step()
+        shards = gatherer.wait() if gatherer is not None else [last["o"]]
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        if rank == 0:
+            np.save(args.dump_wave, torch.cat([x.reshape(x.shape[0], -1) for x in shards], dim=0).cpu().numpy())
 
     tt = torch.tensor([dt, float(valid_samples), dt_nogather or dt], dtype=torch.float64, device=dev)
     rank_ms = [dt_rank / args.steps * 1e3]
@@ -420,6 +467,7 @@ def main():
                                    ", random-init (synthetic) weights of configs/config.json",
                        "utterances_per_gpu": B, "global_batch": B_all * (1 if sharded_global else world),
                        "padded_frames": tf_global, "valid_samples_per_step": int(total_valid),
+                       "frames_padded": int(B * tf_global), "frames_computed": frames_computed,
                        "parallelism": f"shard{world}", "generator": gen_mode, "controls": args.controls},
             "emulated_rank": ({"rank": args.shard_rank, "of": args.shard_of, "utterances": [lo, hi]} if args.shard_of else None),
             "n_ranks_seen": n_ranks_seen,
@@ -438,30 +486,43 @@ def main():
             g = prof["generator"]
             tfl = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0           # algorithmic TFLOP/s
             gbs = g["bytes"] / (g["ms"] * 1e-3) / 1e9 if g["ms"] > 0 else 0.0            # SURVEY 8d bytes / time
+            mvs = g["moved"] / (g["ms"] * 1e-3) / 1e9 if g["ms"] > 0 else 0.0            # bytes moved as fused / time
             mf = {"f32": 1.0, "f16": 1.0}.get(gen_mode, 3.0)                               # MFMA FLOPs issued per algorithmic FLOP
             peak = PEAK_F32_MFMA_TFLOPS if gen_mode == "f32" else PEAK_F16_MFMA_TFLOPS
-            f_hbm, f_mfma, f_alg = gbs / PEAK_HBM_GBS, mf * tfl / peak, tfl / peak
-            # `frac` is the ALGORITHMIC figure: the larger of algorithmic FLOPs / dense MFMA peak and
-            # SURVEY 8d layer-boundary bytes / HBM peak, `bound` naming which roof that is.  The ISSUED matrix rate (three
-            # f16 MFMAs per fp32-accurate product) stays beside it as `mfma_issue_frac`.
+            f_hbm, f_issue, f_alg, f_moved = gbs / PEAK_HBM_GBS, mf * tfl / peak, tfl / peak, mvs / PEAK_HBM_GBS
+            # Which roof.  The work charged follows the work DONE: a trimmed ragged batch is charged
+            # the frames each launch computes (config.frames_computed of frames_padded).  `bound` is the resource the
+            # launches actually saturate first: the ISSUED matrix rate (three f16 MFMAs per fp32-accurate product in the
+            # default mode) against the HBM rate of the bytes the launches MOVE as fused (each operand once; PMC-measured
+            # traffic where profiles/traffic.json has it for this build).  SURVEY 8d's layer-boundary byte model stays in
+            # the line as the contract's algorithmic figure (`hbm_frac`, `alg_gbs`), but it is not a bound of fused
+            # launches -- single fused launches exceed the HBM peak under it -- so it never decides `bound`.
+            # `frac` = ALGORITHMIC work of the bounding resource / its peak, never the issued rate.
+            mfma_bound = f_issue >= f_moved
             roof = ({"bound": "mfma", "achieved": tfl, "peak": peak, "unit": "TFLOP/s", "frac": f_alg}
-                    if f_alg >= f_hbm else
+                    if mfma_bound else
                     {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": f_hbm})
             roof.update({
                 "traffic": None,
-                "kernel": "generator convolutions (g16_conv / g16_convp: one launch per convolution; g16_pp / g16_pair / g16_rw: fused ResBlock conv pairs of the 128- / 64- / 32-channel stages; g16_chain: whole k3 ResBlocks of the 32-channel stage; g16_ups: the streaming up-convs; conv_post), rank 0",
+                "bound_reason": (f"issued matrix work {f_issue:.3f} of the dense peak ({mf:.0f} MFMA per algorithmic product) against "
+                                 f"{f_moved:.3f} of the HBM peak for the bytes the fused launches move; the layer-boundary byte model "
+                                 f"({f_hbm:.3f}) is the contract's algorithmic figure, not a bound of fused launches"),
+                "kernel": "generator convolutions (g16_conv / g16_convp: one launch per convolution; g16_pp / g16_pair / g16_rw: fused ResBlock conv pairs of the 128- / 64- / 32-channel stages; g16_rc: whole k3 ResBlocks of the 32-channel stage; g16_ups: the streaming up-convs; conv_post), rank 0",
                 "launches": g["launches"], "kernel_ms_per_step": g["ms"], "avg_launch_ms": g["ms"] / max(g["launches"], 1),
                 "alg_tflops": tfl, "alg_frac": tfl / peak, "alg_flops_per_launch": g["flops"] / max(g["launches"], 1),
                 "alg_gbs": gbs, "alg_bytes_per_launch": g["bytes"] / max(g["launches"], 1),
                 "alg_gbs_with_residual_reads": g["bytes_ext"] / (g["ms"] * 1e-3) / 1e9 if g["ms"] > 0 else 0.0,
-                "hbm_frac": f_hbm, "mfma_issue_frac": f_mfma, "mfma_issue_tflops": mf * tfl,
+                "moved_gbs": mvs, "moved_bytes_per_launch": g["moved"] / max(g["launches"], 1), "moved_frac_hbm": f_moved,
+                "hbm_frac": f_hbm, "mfma_issue_frac": f_issue, "mfma_issue_tflops": mf * tfl,
+                "work_charged": "frames computed (trimmed tails): config.frames_computed / config.frames_padded of the padded tensor",
                 "dominant_kernel": prof.get("dominant"),
                 "mfma_frac_of_measured_random_data_ceiling": mf * tfl / MEASURED_F16_MFMA_CEILING_TFLOPS if gen_mode != "f32" else None,
                 "hbm_frac_whole_path": value / world * ALG_BYTES_PER_SAMPLE / (PEAK_HBM_GBS * 1e9),
-                "note": "achieved / alg_gbs count SURVEY 8d's layer-boundary bytes (input once + output once per convolution; "
-                        "a fused pair = the two convolutions it replaces = 4 passes), measured with HIP events around every "
-                        "launch in a separate untimed pass; fp32 activations in HBM, f16 MFMA on split operands (3 MFMAs per "
-                        "product) in the default mode",
+                "note": "alg_gbs / hbm_frac count SURVEY 8d's layer-boundary bytes (input once + output once per convolution; "
+                        "a fused pair = the two convolutions it replaces = 4 passes) and moved_* the bytes a launch moves as "
+                        "fused, both for the frames the launches compute, measured with HIP events around every launch in a "
+                        "separate untimed pass; hbm_frac_whole_path = valid samples/s x 13,045 B (SURVEY 8d's own formula); "
+                        "fp32 activations in HBM, f16 MFMA on split operands (3 MFMAs per product) in the default mode",
             })
             at, fr = prof["attention"], prof["frame"]
             if at["ms"] > 0:
@@ -492,6 +553,13 @@ def main():
                         roof["traffic_source"] = "previous PMC pass: " + str(tr.get("source"))
                         roof["traffic_launches"] = tr.get("launches_per_step")   # (the g16_* launches: conv_pre runs on the frame-rate kernel, outside the PMC kernel filter)
                         roof["hbm_measured_gbs"] = tr["hbm_bytes_per_launch"] * tr.get("launches_per_step", g["launches"]) / (g["ms"] * 1e-3) / 1e9
+                        # per-family PMC bytes (tools/pmc_family_traffic.sh): the dominant kernel's MEASURED traffic beside its models
+                        dk = roof.get("dominant_kernel")
+                        fam_tr = (tr.get("families") or {}).get(dk["family"]) if dk else None
+                        if fam_tr:
+                            dk["measured_hbm_bytes_per_launch"] = fam_tr["hbm_bytes_per_launch"]
+                            dk["measured_hbm_gbs"] = fam_tr["hbm_bytes_per_launch"] / (dk["avg_launch_ms"] * 1e-3) / 1e9
+                            dk["measured_frac_hbm"] = dk["measured_hbm_gbs"] / PEAK_HBM_GBS
                 except Exception:
                     pass
             out["roofline"] = roof

@@ -32,7 +32,11 @@ extern "C" {
  * scaled by 2^8 with unscaled lo parts (one fp32 accumulator per tile) -- an arena packed by an ABI-5 library must not be
  * adopted (vsp_commit_adopted_weights checks this number in the arena header) -- and (b) vsp_frame_lengths_host no longer
  * implies a full stream synchronisation after a vsp_encode with given durations (see there). */
-#define VSP_ABI_VERSION 6
+/* 7 (round 6): (a) vsp_status -- sticky numeric-range flags raised by the kernels (see there); (b) the generator's
+ * activations are carried * 2^VSP_ACT_SCALE_LOG2 between conv_pre and conv_post and the packed generator biases carry that
+ * factor: an arena packed by an ABI-6 library (or under another VSP_ACT_SCALE_LOG2: the arena's configuration hash covers it)
+ * must not be adopted. */
+#define VSP_ABI_VERSION 7
 
 enum {
   VSP_OK = 0,
@@ -91,6 +95,22 @@ int vsp_abi_version(void);
 int vsp_create(const vsp_config* cfg, int device, vsp_ctx** out);
 int vsp_destroy(vsp_ctx* ctx);
 const char* vsp_last_error(const vsp_ctx* ctx);
+
+/* Sticky numeric-range flags (ABI 7).  The matrix kernels multiply fp32 activations as f16 hi / lo pairs: an activation
+ * beyond the f16 range (|x| > 65504; inside the generator |x| > 65504 / 2^VSP_ACT_SCALE_LOG2 = 4094 by default) cannot be
+ * split.  It becomes +-inf in the operand (round 5 clamped it silently), so the affected outputs are inf / NaN rather than
+ * plausible wrong numbers, and the last kernels of each half raise a flag in a host-visible word of the context:
+ *   VSP_FLAG_NONFINITE_LATENT  z_p = m_p + noise * exp(logs_p) * noise_scale is not finite somewhere (phoneme- / frame-rate half)
+ *   VSP_FLAG_NONFINITE_WAVE    a waveform sample's pre-tanh sum is not finite (flow or generator)
+ * vsp_status copies the word to *flags (no stream synchronisation: it reflects the launches that have COMPLETED; synchronise
+ * the stream first for a definitive answer) and clears it when `clear` != 0.  Weights outside the packed range are refused at
+ * load time (vsp_finalize_weights); this is the same loudness for activations.  The reference's fp32 path has no such limit.
+ * Precision floor of the split, in terms of OUTPUT level: with the default activation scale the waveform stays within
+ * 1e-4 * max|o| of the fp32 reference down to a peak level of about -90 dBFS (tests/test_amplitude_floor.py measures it;
+ * VSP_ACT_SCALE_LOG2=0, round 5's behaviour, crosses that bound near -68 dBFS). */
+#define VSP_FLAG_NONFINITE_LATENT 1u
+#define VSP_FLAG_NONFINITE_WAVE 2u
+int vsp_status(vsp_ctx* ctx, unsigned* flags, int clear);
 
 /* ---- weights: replaces load_state_dict / utils.load_checkpoint (reference utils.py:21-51) - */
 /* One call per state_dict tensor, raw reference keys ("dec.ups.0.weight_v", ...), float32 HOST
@@ -367,7 +387,13 @@ int vsp_cl_resblock(void* stream, int B, int T, int C, int K, int n_pairs, const
  *                       FLOPs 2 * Cout * Cin * taps * columns * B; bytes = SURVEY.md 8d's
  *                       layer-boundary model, input once + output once per convolution, fp32 (a fused
  *                       pair is charged the two convolutions it replaces = 4 passes); bytes_ext adds
- *                       the residual / accumulate operand reads (5-6 passes per pair);
+ *                       the residual / accumulate operand reads (5-6 passes per pair); bytes_moved
+ *                       (ABI 7) is what the launch must move through HBM AS FUSED -- input, output,
+ *                       residual and previous sum once each: 2-3 passes per fused pair or chain.
+ *                       The layer-boundary model is the contract's algorithmic figure; it is NOT a
+ *                       bound of a fused launch (single launches exceed the HBM peak under it), bytes_moved is.
+ *                       A ragged batch (trimmed tails) is charged the frames each launch COMPUTES
+ *                       (ABI 7; the plan is read back inside profiled passes: one host wait per generator call);
  *   VSP_PROF_ATTENTION  relative-position attention launches (reference attentions.py:148-179):
  *                       FLOPs 4 * H * T^2 (QK^T and PV) + 4 * H * T * (2 window + 1) (banded
  *                       relative terms) per utterance; bytes = q|k|v in + out;
@@ -382,7 +408,7 @@ int vsp_profile_enable(vsp_ctx* ctx, int on);
 int vsp_profile_read(vsp_ctx* ctx, int64_t* launches, double* total_ms, double* total_flops, double* total_bytes,
                      int reset);
 int vsp_profile_read_class(vsp_ctx* ctx, int cls, int64_t* launches, double* total_ms, double* total_flops,
-                           double* total_bytes, double* total_bytes_ext, int reset);
+                           double* total_bytes, double* total_bytes_ext, double* total_bytes_moved, int reset);
 /* ABI 5: the same measurement per KERNEL FAMILY of one class (so that a bench line can name its dominant kernel and a
  * reader can recompute its figures from a rocprofv3 kernel-stats table).  family = kind | log2(channels / 32) << 3 for
  * the generator class (channels = the launch's OUTPUT channels), 0 elsewhere:
@@ -399,7 +425,7 @@ int vsp_profile_read_class(vsp_ctx* ctx, int cls, int64_t* launches, double* tot
 #define VSP_FAM_CHAIN 4
 #define VSP_FAM_PRE 5
 int vsp_profile_read_families(vsp_ctx* ctx, int cls, int max_families, int* family, int64_t* launches, double* total_ms,
-                              double* total_flops, double* total_bytes);
+                              double* total_flops, double* total_bytes, double* total_bytes_moved /* ABI 7, may be NULL */);
 
 #ifdef __cplusplus
 }

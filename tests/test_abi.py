@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), s
     assert sorted(_lib.SIGNATURES) == syms, "ctypes signature table and header disagree"
-    assert lib.vsp_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.vsp_abi_version() == _lib.ABI_VERSION == 7
 
 
 @pytest.fixture()
@@ -191,3 +191,11 @@ def test_typed_weights_and_begin_weights_host_logic(ctx):
         lo, hi = lo - ext, hi + ext
     lo, hi = lo - 3, hi + 3
     assert up == 512 and (back.value, fwd.value) == (hi // up, (up - 1 - lo) // up) == (13, 13)
+
+
+def test_status_word_is_readable_without_a_device(ctx):
+    """vsp_status (ABI 7) before anything has run: no flags, no error; null arguments are refused."""
+    lib, h = ctx
+    flags = C.c_uint(123)
+    assert lib.vsp_status(h, C.byref(flags), 1) == 0 and flags.value == 0
+    assert lib.vsp_status(h, None, 0) == -1 and lib.vsp_status(None, C.byref(flags), 0) == -1

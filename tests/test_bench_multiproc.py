@@ -7,7 +7,9 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -79,3 +81,61 @@ def test_rccl_path_runs_on_hardware_with_one_rank():
     assert d["value"] > 0 and d["config"]["utterances_per_gpu"] == 4 and d["config"]["global_batch"] == 4
     assert "per GPU" in d["config"]["workload"]               # (one GPU: the headline line reads as before)
     assert d["roofline"]["launches"] == 51
+
+
+# ------------------------------------------------------------------------------------------ two RCCL ranks, when the box has them
+# RCCL has never run with more than one rank (no multi-GPU node was available to any round).  These
+# variants are collected everywhere and skipped on one-GPU boxes, so that the FIRST node with >= 2 devices exercises the
+# RCCL broadcast / all-reduce / gather of the path in `pytest -m gpu` before the driver's scaling bench does.
+# (torch.cuda.device_count() does not initialise the GPU; the ranks are fresh child processes of bench.py's self-launch.)
+two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 MI355X: RCCL refuses two ranks on one device")
+
+
+def _one_gpu_wave(tmp_path, *extra):
+    ref = tmp_path / "one_gpu.npy"
+    run_bench(*extra, "--dump-wave", str(ref), "--no-cpu-baseline", gpus=1, backend="nccl")
+    return np.load(ref)
+
+
+@two_gpus
+def test_rccl_two_ranks_strong_form_matches_the_one_gpu_run(tmp_path):
+    """ONE batch of 6 utterances split over two RCCL ranks: weight-arena broadcast + adopt + header check, the frame-count
+    all-reduce MAX, the side-stream gather -- rank 0's gathered waveforms equal the one-GPU run of the same batch."""
+    got = tmp_path / "two_ranks.npy"
+    d = run_bench("--batch", "6", "--dump-wave", str(got), gpus=2, backend="nccl")
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and "nccl" in d["collectives"] and d["scaling"] == "strong"
+    assert d["config"]["global_batch"] == 6 and d["config"]["utterances_per_gpu"] == 3
+    assert d["gather"]["bytes_into_rank0_per_step"] == 4 * 512 * d["config"]["padded_frames"] * 3
+    a, b = np.load(got), _one_gpu_wave(tmp_path, "--batch", "6")
+    assert a.shape == b.shape and np.abs(a - b).max() <= 1e-5 * np.abs(b).max()
+
+
+@two_gpus
+def test_rccl_two_ranks_weak_form(tmp_path):
+    got = tmp_path / "weak.npy"
+    d = run_bench("--batch", "4", "--weak", "--dump-wave", str(got), gpus=2, backend="nccl")
+    assert d["scaling"] == "weak" and d["n_ranks_seen"] == 2 and "nccl" in d["collectives"]
+    assert d["config"]["utterances_per_gpu"] == 4 and d["config"]["global_batch"] == 8
+    assert d["gather"]["bytes_into_rank0_per_step"] == 4 * 512 * d["config"]["padded_frames"] * 4
+    a = np.load(got)
+    assert a.shape[0] == 8 and np.isfinite(a).all() and np.abs(a[4:]).max() > 0        # rank 1's batch arrived
+
+
+@two_gpus
+def test_rccl_two_ranks_c4_form_matches_the_one_gpu_run(tmp_path):
+    got = tmp_path / "c4.npy"
+    d = run_bench("--workload", "C4", "--batch", "6", "--dump-wave", str(got), gpus=2, backend="nccl")
+    assert d["scaling"] == "strong" and d["n_ranks_seen"] == 2 and d["config"]["global_batch"] == 6
+    a, b = np.load(got), _one_gpu_wave(tmp_path, "--workload", "C4", "--batch", "6")
+    assert a.shape == b.shape and np.abs(a - b).max() <= 1e-5 * np.abs(b).max()
+
+
+def test_dump_wave_hook_on_one_gpu_over_gloo(tmp_path):
+    """The hook the two-rank RCCL tests use, exercised on every box: two gloo ranks on one GPU deliver the same
+    waveforms as the one-GPU run of the same batch (global padding, gotcha G6; kernel selection differs with the
+    shard size, hence the tolerance instead of bit equality)."""
+    got = tmp_path / "gloo.npy"
+    d = run_bench("--batch", "6", "--dump-wave", str(got))
+    assert d["n_ranks_seen"] == 2
+    a, b = np.load(got), _one_gpu_wave(tmp_path, "--batch", "6")
+    assert a.shape == b.shape and np.abs(a - b).max() <= 1e-5 * np.abs(b).max()

@@ -14,9 +14,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VSP_LIB_PATH") or os.path.join(_HERE, "lib", "libvispeech_hip.so")
 
 VSP_MAX_LIST = 8
-ABI_VERSION = 6
+ABI_VERSION = 7
 DTYPES = {"float32": 0, "float16": 1, "bfloat16": 2, "float64": 3}   # VSP_DTYPE_*
 PROF_GENERATOR, PROF_ATTENTION, PROF_FRAME = 0, 1, 2
+FLAG_NONFINITE_LATENT, FLAG_NONFINITE_WAVE = 1, 2                    # VSP_FLAG_* (vsp_status)
 
 ERRORS = {0: "VSP_OK", -1: "VSP_ERR_ARG", -2: "VSP_ERR_STATE", -3: "VSP_ERR_HIP", -4: "VSP_ERR_KEY",
           -5: "VSP_ERR_SHAPE", -6: "VSP_ERR_WORKSPACE", -7: "VSP_ERR_UNSUPPORTED"}
@@ -51,6 +52,7 @@ SIGNATURES = {
     "vsp_create": (_I, [C.POINTER(VspConfig), _I, C.POINTER(_P)]),
     "vsp_destroy": (_I, [_P]),
     "vsp_last_error": (C.c_char_p, [_P]),
+    "vsp_status": (_I, [_P, C.POINTER(C.c_uint), _I]),
     "vsp_set_weight": (_I, [_P, C.c_char_p, _P, C.POINTER(_I64), _I]),
     "vsp_set_weight_typed": (_I, [_P, C.c_char_p, _P, C.POINTER(_I64), _I, _I, _I]),
     "vsp_begin_weights": (_I, [_P]),
@@ -104,9 +106,9 @@ SIGNATURES = {
     "vsp_profile_enable": (_I, [_P, _I]),
     "vsp_profile_read": (_I, [_P, C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), _I]),
     "vsp_profile_read_class": (_I, [_P, _I, C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double),
-                                    C.POINTER(C.c_double), C.POINTER(C.c_double), _I]),
+                                    C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), _I]),
     "vsp_profile_read_families": (_I, [_P, _I, _I, C.POINTER(_I), C.POINTER(_I64), C.POINTER(C.c_double),
-                                       C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+                                       C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
 _lib: Optional[C.CDLL] = None

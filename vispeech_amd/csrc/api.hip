@@ -58,8 +58,12 @@ struct Run {
   int rc = VSP_OK;
   // ragged batch of the channels-last generator (kernels.h, ClConvArgs::glen): frames per utterance of the batch chunk
   // being launched, and the columns per frame of the current stage's input / output tensors
+  const int64_t* host_lengths = nullptr;   // the batch's frame counts where the host knows them (vsp_ctx::fl_known), else NULL
   const int* glen = nullptr;
   int grate_in = 0, grate_out = 0;
+  // share of the padded frames the launches of the current generator chunk compute (trimmed tails): the profiled work
+  // of a launch is charged for the frames it processes, not for the padded tensor (set while profiling only)
+  double work_frac = 1.0;
   bool dry() const { return ws.dry; }
   const float* A(size_t off) const { return ctx->arena + off; }
   bool ok() const { return rc == VSP_OK && !ws.overflow; }
@@ -100,21 +104,27 @@ struct Run {
       ctx->ev_fam.resize(ctx->ev_pool.size() / 2, 0);
       ctx->ev_flops.resize(ctx->ev_pool.size() / 2, 0.0);
       ctx->ev_bytes.resize(ctx->ev_pool.size() / 2, 0.0);
+      ctx->ev_moved.resize(ctx->ev_pool.size() / 2, 0.0);
     }
     ctx->ev_cls[ctx->ev_used / 2] = cls;
     ctx->ev_fam[ctx->ev_used / 2] = fam;
     (void)hipEventRecord(ctx->ev_pool[ctx->ev_used], s);
     return true;
   }
-  void prof_end(int cls, double flops, double bytes, double bytes_ext) {
+  // bytes: SURVEY 8d's layer-boundary model (input + output of every CONVOLUTION the launch replaces); bytes_ext: the same
+  // plus residual / accumulate reads; bytes_moved: what the launch moves through HBM as fused (each operand once)
+  void prof_end(int cls, double flops, double bytes, double bytes_ext, double bytes_moved) {
     (void)hipEventRecord(ctx->ev_pool[ctx->ev_used + 1], s);
-    ctx->ev_flops[ctx->ev_used / 2] = flops;
-    ctx->ev_bytes[ctx->ev_used / 2] = bytes;
+    const double f = cls == VSP_PROF_GENERATOR ? work_frac : 1.0;
+    ctx->ev_flops[ctx->ev_used / 2] = flops * f;
+    ctx->ev_bytes[ctx->ev_used / 2] = bytes * f;
+    ctx->ev_moved[ctx->ev_used / 2] = bytes_moved * f;
     ctx->ev_used += 2;
     ctx->prof_launches[cls] += 1;
-    ctx->prof_flops[cls] += flops;
-    ctx->prof_bytes[cls] += bytes;
-    ctx->prof_bytes_ext[cls] += bytes_ext;
+    ctx->prof_flops[cls] += flops * f;
+    ctx->prof_bytes[cls] += bytes * f;
+    ctx->prof_bytes_ext[cls] += bytes_ext * f;
+    ctx->prof_bytes_moved[cls] += bytes_moved * f;
   }
   // fused ResBlock1 chain (g16_chain, gen16.hip): all dilation pairs of one ResBlock in one launch
   // (pairs [p0, p0 + np) of the ResBlock: the whole block by default)
@@ -143,7 +153,7 @@ struct Run {
       // the 2 np convolutions this launch replaces, each charged its input and its output
       const double el = (double)T * ch;
       prof_end(VSP_PROF_GENERATOR, np * 2.0 * 2.0 * ch * ch * rb.k * (double)T * B, 4.0 * B * el * 4.0 * np,
-               4.0 * B * el * (5.0 * np + (acc_prev ? 1.0 : 0.0)));
+               4.0 * B * el * (5.0 * np + (acc_prev ? 1.0 : 0.0)), 4.0 * B * el * (2.0 + (acc_prev ? 1.0 : 0.0)));
     }
   }
   void conv(const ConvArgs& a, int B, bool generator = false) {
@@ -153,8 +163,8 @@ struct Run {
     chk(launch_conv(a, B, s), "conv1d_f32_mfma");
     if (prof) {
       const double in_el = (double)a.T_in * a.Cin, out_el = (double)(a.ups_s > 0 ? a.T_store * (a.M / a.ups_s) : a.Nq * a.M);
-      prof_end(cls, 2.0 * a.M * a.Cin * a.K * (double)a.Nq * B, 4.0 * B * (in_el + out_el),
-               4.0 * B * (in_el + out_el * (1.0 + (a.res ? 1.0 : 0.0) + (a.acc_prev ? 1.0 : 0.0))));
+      const double ext = 4.0 * B * (in_el + out_el * (1.0 + (a.res ? 1.0 : 0.0) + (a.acc_prev ? 1.0 : 0.0)));
+      prof_end(cls, 2.0 * a.M * a.Cin * a.K * (double)a.Nq * B, 4.0 * B * (in_el + out_el), ext, ext);
     }
   }
   // channels-last split-f16 conv: x [B][T_in][Cin] -> out rows of Cout
@@ -187,8 +197,9 @@ struct Run {
     if (prof) {
       // input once + output once; the residual / accumulate reads go to bytes_ext
       const double in_el = (double)T_in * L.Cin, out_el = (double)T_store * L.Cout;
-      prof_end(VSP_PROF_GENERATOR, 2.0 * L.Cout * L.Cin * L.K * L.phases * (double)Nq * B, 4.0 * B * (in_el + out_el),
-               4.0 * B * (in_el + out_el * (1.0 + (res ? 1.0 : 0.0) + (acc_prev ? 1.0 : 0.0))));
+      const double ext = 4.0 * B * (in_el + out_el * (1.0 + (res ? 1.0 : 0.0) + (acc_prev ? 1.0 : 0.0)));
+      prof_end(VSP_PROF_GENERATOR, 2.0 * L.Cout * L.Cin * L.K * L.phases * (double)Nq * B, 4.0 * B * (in_el + out_el), ext,
+               ext + (out && o_img ? 4.0 * B * out_el : 0.0));
     }
   }
   // fused ResBlock1 pair (g16_pair, gen16.hip): out = x + conv2(lrelu(conv1(lrelu(x)))) [+ out] [/ div]
@@ -215,7 +226,7 @@ struct Run {
       // T x C); with conv2's residual read (and the accumulate read of a ResBlock's last pair): 5 (6) -> bytes_ext
       const double el = (double)T * L1.Cout;
       prof_end(VSP_PROF_GENERATOR, 2.0 * 2.0 * L1.Cout * L1.Cin * L1.K * (double)T * B, 4.0 * B * el * 4.0,
-               4.0 * B * el * (5.0 + (acc_prev ? 1.0 : 0.0)));
+               4.0 * B * el * (5.0 + (acc_prev ? 1.0 : 0.0)), 4.0 * B * el * (2.0 + (acc_prev ? 1.0 : 0.0)));
     }
   }
   // cond(g): 1x1 conv on g [B][gin] (T = 1) -> out [B][M]
@@ -266,7 +277,7 @@ void run_encoder_masked(Run& r, const EncoderW& E, int B, int T, T3 x_in, const 
                                c.n_heads, T, c.window_size, r.ctx->att_ksplit, r.s), "attention");
       // QK^T and PV: 2 * h * T^2 MAC per utterance; banded relative logits and values: 2 * h * T * (2w+1) MAC
       if (prof) r.prof_end(VSP_PROF_ATTENTION, (double)B * (4.0 * h * (double)T * T + 4.0 * h * (double)T * (2 * c.window_size + 1)),
-                           4.0 * B * 4.0 * h * (double)T, 4.0 * B * 4.0 * h * (double)T);
+                           4.0 * B * 4.0 * h * (double)T, 4.0 * B * 4.0 * h * (double)T, 4.0 * B * 4.0 * h * (double)T);
     }
     // S = x + conv_o(att)
     a = r.args(L.o, AT, S, T, T);
@@ -444,7 +455,7 @@ void run_generator(Run& r, int B, int T, T3 z, const int64_t* in_lengths, const 
     Tn = Tout;
   }
   if (!r.dry() && r.ok())
-    r.chk(launch_conv_post(X.p, X.bs, X.cs, r.A(m.post_w), m.post_c, m.post_k, 0.01f, o, Tn, B, (int)Tn, r.s),
+    r.chk(launch_conv_post(X.p, X.bs, X.cs, r.A(m.post_w), m.post_c, m.post_k, 0.01f, o, Tn, B, (int)Tn, r.s, r.ctx->flags_dev),
           "conv_post");
 }
 
@@ -520,8 +531,24 @@ void run_generator_cl(Run& r, int B, int T, T3 z, const int64_t* in_lengths, con
   generator_frame_dependence(c, m.g_pre.K, m.post_k, back, fwd);
   int* glen_all = r.ctx->trim_tails ? reinterpret_cast<int*>(r.ws.bytes((size_t)B * sizeof(int))) : nullptr;
   // (gen_tail_fill keeps the computed tensor end -- fwd frames of the waveform -- in 64 KB of LDS: other configurations run untrimmed)
-  const bool trim = glen_all && in_lengths && T > back + fwd + 1 && (size_t)fwd * total_upsample(c) * sizeof(float) <= 64 * 1024;
+  bool trim = glen_all && in_lengths && T > back + fwd + 1 && (size_t)fwd * total_upsample(c) * sizeof(float) <= 64 * 1024;
+  if (trim && r.host_lengths) {
+    // the host knows the frame counts (vsp_frame_lengths_host of this batch): when no utterance ends early enough to be
+    // trimmed (a uniform batch, one long utterance) the kernels run WITHOUT per-utterance extents -- same output, and
+    // the persistent pipelined g16_convp serves the uniform tiles again
+    bool any = false;
+    for (int b = 0; b < B; ++b) any = any || std::max<int64_t>(r.host_lengths[b], 0) + back + 1 + fwd < T;
+    trim = any;
+  }
   if (trim && !r.dry() && r.ok()) r.chk(launch_gen_plan(in_lengths, B, T, back, fwd, glen_all, r.s), "gen_plan");
+  // profiled (untimed) passes charge every launch the frames it COMPUTES: read the plan back (a host wait -- profiling only)
+  std::vector<int> glen_host;
+  if (trim && r.ctx->prof_on && !r.dry() && r.ok()) {
+    glen_host.resize(B);
+    hipError_t e = hipMemcpyAsync(glen_host.data(), glen_all, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, r.s);
+    if (e == hipSuccess) e = hipStreamSynchronize(r.s);
+    r.chk(e, "gen_plan read-back (profiling)");
+  }
   // the channels-last kernels address one utterance's tensor with 32-bit byte offsets (buffer descriptors)
   // (the operand images -- C * 4 * (T + 384) bytes per utterance -- are addressed the same way)
   if (mx * sizeof(float) >= (size_t)1 << 31 || (timg && mx_img * sizeof(float) >= (size_t)1 << 31)) {
@@ -536,7 +563,7 @@ void run_generator_cl(Run& r, int B, int T, T3 z, const int64_t* in_lengths, con
   r.conv(a, B, true);
   int cur = 0;
   if (!r.dry() && r.ok())
-    r.chk(launch_transpose_ct(X0.p, X0.bs, X0.cs, buf[cur], (long)T * c0, c0, B, c0, T, r.s), "transpose");
+    r.chk(launch_transpose_ct(X0.p, X0.bs, X0.cs, buf[cur], (long)T * c0, c0, B, c0, T, r.s, r.ctx->act_scale), "transpose");
   long Tn = T;
   int ch = c0;
   for (int i = 0; i < c.n_upsamples; ++i) {
@@ -565,6 +592,12 @@ void run_generator_cl(Run& r, int B, int T, T3 z, const int64_t* in_lengths, con
       const int nb = std::min(Bc, B - b0);
       r.glen = trim ? glen_all + b0 : nullptr;
       r.grate_in = (int)(Tn / T); r.grate_out = (int)(Tout / T);
+      r.work_frac = 1.0;
+      if (!glen_host.empty() && r.ok()) {
+        double fr = 0.0;
+        for (int b = b0; b < b0 + nb; ++b) fr += glen_host[b];
+        r.work_frac = fr / ((double)nb * T);
+      }
       const float* xin = buf[cur] + (size_t)b0 * xbs;
       float *xu = XU + (size_t)b0 * bs, *xs = XS + (size_t)b0 * bs;
       r.clconv(U, xin, xbs, xu, bs, nullptr, 0, (int)Tn, (int)Tn + 1, (int)Tout, 0.1f, false, 1.f, nb);
@@ -652,9 +685,10 @@ void run_generator_cl(Run& r, int B, int T, T3 z, const int64_t* in_lengths, con
     Tn = Tout;
   }
   r.glen = nullptr;
+  r.work_frac = 1.0;
   if (!r.dry() && r.ok()) {
     r.chk(launch_conv_post_cl(buf[cur], Tn * ch, ch, r.A(m.post_wt), m.post_c, m.post_k, 0.01f, o, Tn, B, (int)Tn, r.s,
-                              trim ? glen_all : nullptr, (int)(Tn / T)), "conv_post_cl");
+                              trim ? glen_all : nullptr, (int)(Tn / T), 1.f / r.ctx->act_scale, r.ctx->flags_dev), "conv_post_cl");
     if (trim) r.chk(launch_gen_tail_fill(o, Tn, in_lengths, glen_all, B, T, back, fwd, (int)(Tn / T), r.s), "gen_tail_fill");
   }
 }
@@ -734,6 +768,10 @@ int vsp_create(const vsp_config* cfg, int device, vsp_ctx** out) {
   if (const char* e = getenv("VSP_CHAIN")) ctx->chain_mask = atoi(e);
   if (const char* e = getenv("VSP_RW64")) ctx->rw64 = atoi(e) != 0;               // 1: g16_rw64 for the 64-channel k3 pairs (opt-in)
   if (const char* e = getenv("VSP_TRIM_TAILS")) ctx->trim_tails = atoi(e) != 0;   // 0: every utterance runs to the padded length
+  if (const char* e = getenv("VSP_ACT_SCALE_LOG2")) {                             // model.h: the generator's activation scale
+    const int l = atoi(e);
+    ctx->act_scale = std::ldexp(1.f, l < 0 ? 0 : l > 8 ? 8 : l);
+  }
   if (const char* e = getenv("VSP_EARLY_FL")) ctx->early_fl = atoi(e) != 0;
   if (const char* e = getenv("VSP_RB_STREAMS")) ctx->rb_streams = atoi(e);   // stage mask: ResBlock chains on side streams (opt-in, measured slower)
 #ifdef VSP_EXPERIMENTS
@@ -755,6 +793,7 @@ int vsp_destroy(vsp_ctx* ctx) {
   for (auto e : ctx->sync_ev) (void)hipEventDestroy(e);
   if (ctx->fl_ev) (void)hipEventDestroy(ctx->fl_ev);
   if (ctx->fl_pinned) (void)hipHostFree(ctx->fl_pinned);
+  if (ctx->flags_host) (void)hipHostFree(ctx->flags_host);
   for (auto st : ctx->side) if (st) (void)hipStreamDestroy(st);
   if (ctx->arena && ctx->arena_owned) (void)hipFree(ctx->arena);
   delete ctx;
@@ -762,6 +801,15 @@ int vsp_destroy(vsp_ctx* ctx) {
 }
 
 const char* vsp_last_error(const vsp_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int vsp_status(vsp_ctx* ctx, unsigned* flags, int clear) {
+  if (!ctx || !flags) return VSP_ERR_ARG;
+  *flags = 0u;
+  if (!ctx->flags_host) return VSP_OK;                 // (nothing has run on this context yet)
+  volatile unsigned* w = ctx->flags_host;
+  *flags = clear ? __atomic_exchange_n(ctx->flags_host, 0u, __ATOMIC_ACQ_REL) : *w;
+  return VSP_OK;
+}
 
 int vsp_begin_weights(vsp_ctx* ctx) {
   if (!ctx) return VSP_ERR_ARG;
@@ -881,7 +929,25 @@ int64_t vsp_weight_arena_bytes(const vsp_ctx* ctx) {
   return ctx ? (int64_t)(ctx->model.total_floats * sizeof(float)) : VSP_ERR_ARG;
 }
 
+// The status word (vsp_status): pinned host memory mapped into the device's address space, so that reading it costs no
+// stream synchronisation; the kernels touch it only when they have something to report.
+static int ensure_flags(vsp_ctx* ctx) {
+  if (ctx->flags_host) return VSP_OK;
+  void* h = nullptr;
+  void* d = nullptr;
+  hipError_t e = hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable);
+  if (e == hipSuccess) { *static_cast<unsigned*>(h) = 0u; e = hipHostGetDevicePointer(&d, h, 0); }
+  if (e != hipSuccess) {
+    if (h) (void)hipHostFree(h);
+    return ctx->fail(VSP_ERR_HIP, "status word (hipHostMalloc): %s", hipGetErrorString(e));
+  }
+  ctx->flags_host = static_cast<unsigned*>(h);
+  ctx->flags_dev = static_cast<unsigned*>(d);
+  return VSP_OK;
+}
+
 static int set_arena(vsp_ctx* ctx, void* dev_arena) {
+  if (int rc = ensure_flags(ctx)) return rc;
   if (ctx->arena && ctx->arena_owned && ctx->arena != dev_arena) (void)hipFree(ctx->arena);
   if (dev_arena) {
     ctx->arena = (float*)dev_arena;
@@ -907,6 +973,7 @@ static uint32_t config_hash(const vsp_ctx* ctx) {
   mix(&ctx->cfg, sizeof ctx->cfg);
   const int sw[3] = {ctx->frame_f16s ? 1 : 0, ctx->model.has_cl ? 1 : 0, ctx->gen_mode != 0 ? 1 : 0};
   mix(sw, sizeof sw);
+  mix(&ctx->act_scale, sizeof ctx->act_scale);   // (the packed generator biases carry it)
   return h;
 }
 
@@ -998,7 +1065,8 @@ static bool early_frame_lengths_ready(vsp_ctx* ctx, int B) {
 static int encode_impl(vsp_ctx* ctx, hipStream_t s, Ws& ws, int B, int Tp, const int64_t* phonemes,
                        const int64_t* lengths, const int64_t* sid, const float* dctl, const float* pctl,
                        const float* ectl, float dscale, float pscale, float escale, float* x_var, float* g,
-                       float* duration, float* f0, float* energy, int64_t* frame_lengths, int32_t* cum_dur) {
+                       float* duration, float* f0, float* energy, int64_t* frame_lengths, int32_t* cum_dur,
+                       bool early_copy = true) {
   const vsp_config& c = ctx->cfg;
   const Model& m = ctx->model;
   const int h = c.hidden_channels, gin = c.gin_channels;
@@ -1020,11 +1088,12 @@ static int encode_impl(vsp_ctx* ctx, hipStream_t s, Ws& ws, int B, int Tp, const
   }
   // ---- given durations (models.py:681): the frame counts need nothing computed here -- derive them FIRST and start their
   // copy to the host, so that vsp_frame_lengths_host returns while the text encoder runs (vsp_ctx::fl_pinned)
-  if (live) ctx->fl_src = nullptr;
+  if (live) { ctx->fl_src = nullptr; ctx->fl_known_src = nullptr; }
   if (dctl && live) {
     r.chk(hipMemcpyAsync(duration, dctl, (size_t)B * Tp * sizeof(float), hipMemcpyDeviceToDevice, s), "dur copy");
     r.chk(launch_duration_cumsum(duration, cum_dur, frame_lengths, B, Tp, s), "duration cumsum");
-    if (r.ok() && ctx->early_fl && early_frame_lengths_ready(ctx, B)) {
+    // (early_copy == false: the one-call form vsp_infer never reads the counts back -- nothing would consume the copy)
+    if (r.ok() && early_copy && ctx->early_fl && early_frame_lengths_ready(ctx, B)) {
       hipError_t e = hipMemcpyAsync(ctx->fl_pinned, frame_lengths, (size_t)B * sizeof(int64_t), hipMemcpyDeviceToHost, s);
       if (e == hipSuccess) e = hipEventRecord(ctx->fl_ev, s);
       if (e == hipSuccess) { ctx->fl_src = frame_lengths; ctx->fl_n = B; }
@@ -1134,6 +1203,8 @@ int vsp_frame_lengths_host(vsp_ctx* ctx, void* stream, int B, const int64_t* fra
   int64_t mx = 0;
   for (int b = 0; b < B; ++b) mx = std::max(mx, frame_lengths_host[b]);
   *max_frames = mx;
+  ctx->fl_known.assign(frame_lengths_host, frame_lengths_host + B);   // (model.h: until the next vsp_encode)
+  ctx->fl_known_src = frame_lengths_dev;
   return VSP_OK;
 }
 
@@ -1146,6 +1217,7 @@ static int decode_impl(vsp_ctx* ctx, hipStream_t s, Ws& ws, int B, int Tp, int T
   const Model& m = ctx->model;
   const int h = c.hidden_channels, inter = c.inter_channels;
   Run r{ctx, s, ws};
+  if (frame_lengths && ctx->fl_known_src == frame_lengths && (int)ctx->fl_known.size() == B) r.host_lengths = ctx->fl_known.data();
   T3 XF = ws.t3(B, h, Tf), HF = ws.t3(B, h, Tf);
   // noise == NULL: the library draws it (Philox4x32-10 keyed by noise_seed) -- the torch.randn_like of models.py:718
   float* drawn = ws.f((size_t)B * inter * Tf);
@@ -1167,7 +1239,7 @@ static int decode_impl(vsp_ctx* ctx, hipStream_t s, Ws& ws, int B, int Tp, int T
   r.conv(a, B);
   if (live) {
     const long n = (long)B * inter * Tf;
-    r.chk(launch_reparam(m_p, logs_p, noise, noise_scale, z_p, n, s, z), "reparam");   // (z = z_p: the flow transforms z in place)
+    r.chk(launch_reparam(m_p, logs_p, noise, noise_scale, z_p, n, s, z, ctx->flags_dev), "reparam");   // (z = z_p: the flow transforms z in place)
   }
   run_flow(r, B, Tf, Z, g, frame_lengths);
   const int Tdec = max_len < 0 ? Tf : std::min(Tf, max_len);
@@ -1213,7 +1285,7 @@ static int infer_impl(vsp_ctx* ctx, hipStream_t s, Ws& ws, int B, int Tp, int Tf
   int32_t* cum = (int32_t*)ws.bytes((size_t)B * Tp * sizeof(int32_t));
   const size_t mark = ws.cur;
   int rc = encode_impl(ctx, s, ws, B, Tp, phonemes, lengths, sid, dctl, pctl, ectl, dsc, psc, esc, x_var, g, duration,
-                       f0, energy, frame_lengths, cum);
+                       f0, energy, frame_lengths, cum, /*early_copy=*/false);
   const size_t after_enc = ws.cur;
   ws.cur = mark;                 // the two halves run one after the other on one stream: shared scratch
   if (rc == VSP_OK)
@@ -1933,7 +2005,7 @@ int vsp_profile_enable(vsp_ctx* ctx, int on) {
     ctx->ev_used = 0;
     for (int c = 0; c < VSP_PROF_CLASSES; ++c) {
       ctx->prof_launches[c] = 0;
-      ctx->prof_flops[c] = ctx->prof_bytes[c] = ctx->prof_bytes_ext[c] = 0.0;
+      ctx->prof_flops[c] = ctx->prof_bytes[c] = ctx->prof_bytes_ext[c] = ctx->prof_bytes_moved[c] = 0.0;
     }
   }
   ctx->prof_on = on != 0;
@@ -1941,7 +2013,7 @@ int vsp_profile_enable(vsp_ctx* ctx, int on) {
 }
 
 int vsp_profile_read_class(vsp_ctx* ctx, int cls, int64_t* launches, double* total_ms, double* total_flops,
-                           double* total_bytes, double* total_bytes_ext, int reset) {
+                           double* total_bytes, double* total_bytes_ext, double* total_bytes_moved, int reset) {
   if (!ctx || cls < 0 || cls >= VSP_PROF_CLASSES || !launches || !total_ms || !total_flops || !total_bytes)
     return ctx ? ctx->fail(VSP_ERR_ARG, "vsp_profile_read_class: bad argument") : VSP_ERR_ARG;
   double ms = 0.0;
@@ -1958,11 +2030,12 @@ int vsp_profile_read_class(vsp_ctx* ctx, int cls, int64_t* launches, double* tot
   *total_flops = ctx->prof_flops[cls];
   *total_bytes = ctx->prof_bytes[cls];
   if (total_bytes_ext) *total_bytes_ext = ctx->prof_bytes_ext[cls];
+  if (total_bytes_moved) *total_bytes_moved = ctx->prof_bytes_moved[cls];
   if (reset) {
     // the event pool is shared: drop every class's events only when the LAST class has been read; a reset of one
     // class zeroes its counters and marks its pairs as consumed
     ctx->prof_launches[cls] = 0;
-    ctx->prof_flops[cls] = ctx->prof_bytes[cls] = ctx->prof_bytes_ext[cls] = 0.0;
+    ctx->prof_flops[cls] = ctx->prof_bytes[cls] = ctx->prof_bytes_ext[cls] = ctx->prof_bytes_moved[cls] = 0.0;
     bool any = false;
     for (size_t i = 0; i + 1 < ctx->ev_used; i += 2) {
       if (ctx->ev_cls[i / 2] == cls) ctx->ev_cls[i / 2] = -1;
@@ -1974,7 +2047,7 @@ int vsp_profile_read_class(vsp_ctx* ctx, int cls, int64_t* launches, double* tot
 }
 
 int vsp_profile_read_families(vsp_ctx* ctx, int cls, int max_families, int* family, int64_t* launches, double* total_ms,
-                              double* total_flops, double* total_bytes) {
+                              double* total_flops, double* total_bytes, double* total_bytes_moved) {
   if (!ctx || cls < 0 || cls >= VSP_PROF_CLASSES || max_families < 0 || !family || !launches || !total_ms || !total_flops ||
       !total_bytes)
     return ctx ? ctx->fail(VSP_ERR_ARG, "vsp_profile_read_families: bad argument") : VSP_ERR_ARG;
@@ -1991,19 +2064,21 @@ int vsp_profile_read_families(vsp_ctx* ctx, int cls, int max_families, int* fami
     if (k == n) {
       if (n == max_families) continue;
       family[n] = f; launches[n] = 0; total_ms[n] = total_flops[n] = total_bytes[n] = 0.0;
+      if (total_bytes_moved) total_bytes_moved[n] = 0.0;
       ++n;
     }
     launches[k] += 1;
     total_ms[k] += t;
     total_flops[k] += ctx->ev_flops[i / 2];
     total_bytes[k] += ctx->ev_bytes[i / 2];
+    if (total_bytes_moved) total_bytes_moved[k] += ctx->ev_moved[i / 2];
   }
   return n;
 }
 
 int vsp_profile_read(vsp_ctx* ctx, int64_t* launches, double* total_ms, double* total_flops, double* total_bytes,
                      int reset) {
-  return vsp_profile_read_class(ctx, VSP_PROF_GENERATOR, launches, total_ms, total_flops, total_bytes, nullptr, reset);
+  return vsp_profile_read_class(ctx, VSP_PROF_GENERATOR, launches, total_ms, total_flops, total_bytes, nullptr, nullptr, reset);
 }
 
 }  // extern "C"

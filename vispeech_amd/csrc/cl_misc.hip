@@ -9,7 +9,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // ------------------------------------------------------------------------------------------
 // [B][C][T] -> [B][T][C] (conv_pre's output enters the channels-last vocoder), 32x32 LDS tiles
 __global__ void __launch_bounds__(256) transpose_ct_kernel(const float* __restrict__ x, long x_bs, long x_cs,
-                                                           float* __restrict__ y, long y_bs, int y_ts, int C, int T) {
+                                                           float* __restrict__ y, long y_bs, int y_ts, int C, int T,
+                                                           float scale) {
   __shared__ float tile[32][33];
   const int b = blockIdx.z, c0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
   const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;  // 32 x 8
@@ -22,13 +23,13 @@ __global__ void __launch_bounds__(256) transpose_ct_kernel(const float* __restri
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int t = t0 + ly + 8 * k, c = c0 + lx;
-    if (t < T && c < C) y[(size_t)b * y_bs + (size_t)t * y_ts + c] = tile[lx][ly + 8 * k];
+    if (t < T && c < C) y[(size_t)b * y_bs + (size_t)t * y_ts + c] = tile[lx][ly + 8 * k] * scale;
   }
 }
 hipError_t launch_transpose_ct(const float* x, long x_bs, long x_cs, float* y, long y_bs, int y_ts, int B, int C,
-                               int T, hipStream_t s) {
+                               int T, hipStream_t s, float scale) {
   hipLaunchKernelGGL(transpose_ct_kernel, dim3((T + 31) / 32, (C + 31) / 32, B), dim3(256), 0, s, x, x_bs, x_cs, y,
-                     y_bs, y_ts, C, T);
+                     y_bs, y_ts, C, T, scale);
   return hipGetLastError();
 }
 
@@ -44,7 +45,8 @@ template <int C>
 __global__ void __launch_bounds__(256) conv_post_cl_kernel(const float* __restrict__ x, long x_bs,
                                                            const float* __restrict__ wt /* [K][C] */, int K,
                                                            float slope, float* __restrict__ o, long o_bs, int T,
-                                                           const int* __restrict__ glen, int grate) {
+                                                           const int* __restrict__ glen, int grate, float unscale,
+                                                           unsigned* __restrict__ flags) {
   constexpr int RSF = C + 4;
   constexpr int C4 = C / 4;
   __shared__ __attribute__((aligned(16))) float xs[(CPL_TILE + 8) * RSF];
@@ -80,16 +82,25 @@ __global__ void __launch_bounds__(256) conv_post_cl_kernel(const float* __restri
       acc += wr[4 * c4 + 3] * xv.w;
     }
   }
-  if (t < T) o[(size_t)b * o_bs + t] = tanhf(acc);
+  // (the generator's activations arrive * the context's activation scale -- every layer between conv_pre and here is
+  // positively homogeneous once the biases carry the scale too; conv_post has no bias: the sum is unscaled here, exactly)
+  acc *= unscale;
+  if (t < T) {
+    o[(size_t)b * o_bs + t] = tanhf(acc);
+    // an activation beyond the split-f16 range turns into inf / NaN inside the matrix kernels (g16_common.h) and arrives
+    // here: raise the context's sticky flag (vsp_status) -- rare, so the atomic costs nothing
+    if (flags && !(fabsf(acc) <= 3.0e38f)) atomicOr(flags, VSP_FLAG_NONFINITE_WAVE);
+  }
 }
 hipError_t launch_conv_post_cl(const float* x, long x_bs, int x_ts, const float* w, int C, int K, float slope,
-                               float* o, long o_bs, int B, int T, hipStream_t s, const int* glen, int grate) {
+                               float* o, long o_bs, int B, int T, hipStream_t s, const int* glen, int grate, float unscale,
+                               unsigned* flags) {
   if (K > 8 || x_ts != C || (C != 32 && C != 64)) return hipErrorInvalidValue;
   dim3 grid((T + CPL_TILE - 1) / CPL_TILE, B);
   if (C == 32)
-    hipLaunchKernelGGL(conv_post_cl_kernel<32>, grid, dim3(256), 0, s, x, x_bs, w, K, slope, o, o_bs, T, glen, grate);
+    hipLaunchKernelGGL(conv_post_cl_kernel<32>, grid, dim3(256), 0, s, x, x_bs, w, K, slope, o, o_bs, T, glen, grate, unscale, flags);
   else
-    hipLaunchKernelGGL(conv_post_cl_kernel<64>, grid, dim3(256), 0, s, x, x_bs, w, K, slope, o, o_bs, T, glen, grate);
+    hipLaunchKernelGGL(conv_post_cl_kernel<64>, grid, dim3(256), 0, s, x, x_bs, w, K, slope, o, o_bs, T, glen, grate, unscale, flags);
   return hipGetLastError();
 }
 

@@ -598,13 +598,8 @@ __global__ void __launch_bounds__(64 * WM * WN, F16S ? 2 : 1) conv1d_f32_mfma(Co
       }
   unsigned* const ph = reinterpret_cast<unsigned*>(xs);          // F16S: hi image [16][LWP] words
   unsigned* const pl = ph + (CONV_CK / 2) * LWP;                 //       lo image
-  // hi = the fp32 value truncated to f16 precision (one v_and_b32; packed without rounding by v_cvt_pkrtz, which also
-  // saturates instead of producing inf), lo = the exact fp32 residual (g16_common.h: g16_split2)
-  auto split_pair = [&](float x0, float x1, unsigned& whi, unsigned& wlo) {
-    const float h0 = __uint_as_float(__float_as_uint(x0) & 0xffffe000u), h1 = __uint_as_float(__float_as_uint(x1) & 0xffffe000u);
-    whi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h0, h1));
-    wlo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0 - h0, x1 - h1));
-  };
+  // hi = the fp32 values rounded to f16 (inf beyond the f16 range), lo = the exact residual (kernels.h: vsp_split_pair)
+  auto split_pair = [&](float x0, float x1, unsigned& whi, unsigned& wlo) { vsp_split_pair(x0, x1, whi, wlo); };
 
   const float4* wp4 = reinterpret_cast<const float4*>(a.wp);
   float4 a_cur[MT][KG], a_nxt[MT][KG];
@@ -714,10 +709,7 @@ __global__ void __launch_bounds__(64 * WM * WN, F16S ? 2 : 1) conv1d_f32_mfma(Co
         const f32x2v y = x * slope_eff;
         asm("v_max_f32 %0, %1, %2" : "=v"(x.x) : "v"(x.x), "v"(y.x));
         asm("v_max_f32 %0, %1, %2" : "=v"(x.y) : "v"(x.y), "v"(y.y));
-        const f32x2v hf = {__uint_as_float(__float_as_uint(x.x) & 0xffffe000u), __uint_as_float(__float_as_uint(x.y) & 0xffffe000u)};
-        const f32x2v lf = x - hf;                       // (unscaled: ONE accumulator, g16_common.h)
-        wh4[u] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(hf.x, hf.y));
-        wl4[u] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lf.x, lf.y));
+        vsp_split_pair(x.x, x.y, wh4[u], wl4[u]);       // (kernels.h; unscaled lo parts: ONE accumulator)
       }
       const int o = (wave + j * NW) * LWP + 4 * lane;
       *reinterpret_cast<u32x4*>(ph + o) = u32x4{wh4[0], wh4[1], wh4[2], wh4[3]};
@@ -1226,10 +1218,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 1) conv_frame_f16s(ConvArgs a) {
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const f32x2v x = {va[q][u], vb[q][u]};
-            const f32x2v hf = {__uint_as_float(__float_as_uint(x.x) & 0xffffe000u), __uint_as_float(__float_as_uint(x.y) & 0xffffe000u)};
-            const f32x2v lf = x - hf;
-            wh4[u] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(hf.x, hf.y));
-            wl4[u] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lf.x, lf.y));
+            vsp_split_pair(x.x, x.y, wh4[u], wl4[u]);       // (kernels.h; unscaled lo parts: ONE accumulator)
           }
         } else {
           const int ci = chunk * CONV_CK + 2 * p;
@@ -1244,10 +1233,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 1) conv_frame_f16s(ConvArgs a) {
             const f32x2v y = x * slope_eff;
             asm("v_max_f32 %0, %1, %2" : "=v"(x.x) : "v"(x.x), "v"(y.x));
             asm("v_max_f32 %0, %1, %2" : "=v"(x.y) : "v"(x.y), "v"(y.y));
-            const f32x2v hf = {__uint_as_float(__float_as_uint(x.x) & 0xffffe000u), __uint_as_float(__float_as_uint(x.y) & 0xffffe000u)};
-            const f32x2v lf = x - hf;
-            wh4[u] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(hf.x, hf.y));
-            wl4[u] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lf.x, lf.y));
+            vsp_split_pair(x.x, x.y, wh4[u], wl4[u]);       // (kernels.h; unscaled lo parts: ONE accumulator)
           }
         }
         *reinterpret_cast<u32x4*>(slot + (p * LWP4 + lane) * 16) = u32x4{wh4[0], wh4[1], wh4[2], wh4[3]};
@@ -1537,10 +1523,7 @@ __global__ void __launch_bounds__(256, 1) conv_frame_splitk(ConvArgs a) {
         const f32x2v y = x * slope_eff;
         asm("v_max_f32 %0, %1, %2" : "=v"(x.x) : "v"(x.x), "v"(y.x));
         asm("v_max_f32 %0, %1, %2" : "=v"(x.y) : "v"(x.y), "v"(y.y));
-        const f32x2v hf = {__uint_as_float(__float_as_uint(x.x) & 0xffffe000u), __uint_as_float(__float_as_uint(x.y) & 0xffffe000u)};
-        const f32x2v lf = x - hf;
-        wh4[u] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(hf.x, hf.y));
-        wl4[u] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lf.x, lf.y));
+        vsp_split_pair(x.x, x.y, wh4[u], wl4[u]);       // (kernels.h; unscaled lo parts: ONE accumulator)
       }
       const int o = xp[it] * LWP + (xt[it] - t_start);
       *reinterpret_cast<u32x4*>(ph + o) = u32x4{wh4[0], wh4[1], wh4[2], wh4[3]};

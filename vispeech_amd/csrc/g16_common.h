@@ -104,19 +104,18 @@ __device__ __forceinline__ void g16_for(F&& f) {
 }
 
 // leaky-relu + split of four fp32 values -> hi / lo f16x4.
-// Built from the fewest vector instructions that keep the split exact (round 3: 16 per four values + 8 for the leaky-relu
-// instead of 32; round 5: 12 + 8, the lo parts are no longer scaled -- "ONE accumulator per tile" below):
-//   hi = x with the mantissa TRUNCATED to f16 precision: one v_and_b32 on the fp32 bits (0xffffe000); exactly
-//        representable in f16 over the normal range, so v_cvt_pkrtz_f16_f32 packs two of them in ONE instruction
-//        without rounding (and saturates at the largest finite f16 instead of producing inf);
-//   lo = x - hi: exact in fp32 (no conversion back from f16); packed by v_cvt_pkrtz as well.  |lo| <= 2^-10 |x|: a normal
-//        f16 number while |x| >= 2^-4, an f16 SUBNORMAL below (the packing then truncates it to a multiple of 2^-24).
-// So hi + lo keeps 21 bits of x where |x| >= 2^-4 and x to within 2^-24 ABSOLUTE below -- activations of 1e-2 .. 1e-1
-// keep 17-20 bits.  In a dot product that is |error| <= 2^-24 sum|w| per output, the same bound the round-3 form had for
-// |x| < 2^-14 only, and below the fp32 accumulation noise of a 96 .. 2816-term sum against outputs of O(1e-2 .. 1)
-// (measured: waveform error against the fp64 oracle 1.5e-6 before, 1.9e-6 now; tests/test_cl_ops.py holds the bound with
-// every activation at 1e-5 and a relative 1e-6 with weights of 1e-3).  Every generator kernel splits with this one
-// function, so the ResBlock implementations stay bit-identical.
+// The split itself is kernels.h vsp_split_pair (round 6: FOUR vector instructions per two values -- one v_cvt_pk_f16_f32 for
+// both hi parts, one v_fma_mix_f32 per lo part, one v_cvt_pkrtz for both lo parts; rounds 3-5: six, round 2: sixteen),
+// + 2 per value for the leaky-relu: 16 per four values where round 5 had 20.
+//   hi = x ROUNDED to f16 (inf beyond the f16 range: loud, vsp_status -- rounds 2-5 saturated at 65504 silently);
+//   lo = x - hi, exact in fp32, packed by truncation: |lo| <= 2^-11 |x| -- a normal f16 number while |x| >= 2^-3, an f16
+//        SUBNORMAL below (a multiple of 2^-24).
+// So hi + lo keeps 22 bits of x where |x| >= 2^-3 and x to within 2^-24 ABSOLUTE below.  In a dot product that is
+// |error| <= 2^-24 sum|w| per output: below the fp32 accumulation noise of a 96 .. 2816-term sum against outputs of
+// O(1e-2 .. 1); where the output LEVEL makes it visible is measured in tests/test_amplitude_floor.py, and the generator
+// carries its activations * 2^4 (model.h act_scale) to push that level down to about -92 dBFS.  tests/test_cl_ops.py holds
+// the absolute bound with every activation at 1e-5 and a relative 1e-6 with weights of 1e-3.  Every generator kernel
+// splits with this one function, so the ResBlock implementations stay bit-identical.
 // G16_SPLIT_PLAIN (late round 4): the subtraction and the leaky-relu scaling as PLAIN f32 instructions (asm, so that hipcc does not
 // SLP-pack them): beside an MFMA stream a v_pk_*_f32 costs far more issue time than the two plain instructions it
 // replaces (MI355X_MICROARCH.md, constants table: "an anti-lever beside MFMAs"), and these kernels' vector work runs
@@ -138,16 +137,10 @@ __device__ __forceinline__ void g16_for(F&& f) {
 // Measured: step 71.4 -> 68.9 ms same box with every parity test green (profiles/r05_one_accumulator.txt).
 // (G16_WSCALE / G16_UNSCALE: kernels.h)
 __device__ __forceinline__ void g16_split2(f32x2 x, f16x2& h, f16x2& l) {
-  const f32x2 hf = {__uint_as_float(__float_as_uint(x.x) & 0xffffe000u), __uint_as_float(__float_as_uint(x.y) & 0xffffe000u)};
-#if G16_SPLIT_PLAIN
-  f32x2 lf;
-  asm("v_sub_f32 %0, %1, %2" : "=v"(lf.x) : "v"(x.x), "v"(hf.x));
-  asm("v_sub_f32 %0, %1, %2" : "=v"(lf.y) : "v"(x.y), "v"(hf.y));
-#else
-  const f32x2 lf = x - hf;
-#endif
-  h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(hf.x, hf.y));
-  l = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(lf.x, lf.y));
+  unsigned hi, lo;
+  vsp_split_pair(x.x, x.y, hi, lo);          // (kernels.h: round 6's four-instruction form)
+  h = __builtin_bit_cast(f16x2, hi);
+  l = __builtin_bit_cast(f16x2, lo);
 }
 __device__ __forceinline__ void g16_split4(const f32x4 v, float slope, bool act, f16x4& eh, f16x4& el) {
 #pragma unroll

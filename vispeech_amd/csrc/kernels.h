@@ -5,6 +5,8 @@
 
 #include <atomic>
 
+#include "../../include/vispeech_hip.h"   // (VSP_FLAG_*: the sticky status bits the kernels raise)
+
 namespace vsp {
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is set per DEVICE: a process may hold contexts on several GPUs (vsp_create
@@ -74,6 +76,42 @@ void pack_conv_weights_f16s(float* dst, int M, int Cin, int K, const float* dens
 #define G16_UNSCALE_V (1.f / 256.f)
 #endif
 constexpr float G16_WSCALE = G16_WSCALE_V, G16_UNSCALE = G16_UNSCALE_V;
+
+#ifdef __HIPCC__
+// THE operand split of two fp32 values into f16 hi / lo pairs (hi | lo packed two per register), shared by every split-f16
+// kernel (g16_common.h g16_split2; conv_mfma.hip) -- one function, so that the implementations stay bit-identical.
+// Round 6 form, FOUR vector instructions per two values (rounds 3-5: six):
+//   hi  = v_cvt_pk_f16_f32(x0, x1): both values ROUNDED to f16 (nearest even) in one instruction; +-inf beyond the f16
+//         range -- an activation the split cannot represent poisons the product (inf / NaN down to the waveform, where
+//         conv_post raises the context's sticky flag: vsp_status) where rounds 2-5's v_cvt_pkrtz saturated silently;
+//   lo  = x - hi: v_fma_mix_f32 reads the f16 half directly (hi * -1.0 + x, ONE rounding of an exactly representable
+//         difference: exact), so no v_and_b32 truncation and no conversion back -- one instruction per value;
+//   lo pair packed by v_cvt_pkrtz_f16_f32 (|lo| <= 2^-11 |x|: 13 significant bits truncated to f16's 11, i.e. x to
+//         2^-22 relative; an f16 subnormal -- multiples of 2^-24 -- where |x| < 2^-3).
+// Rounds 3-5 cut the mantissa (v_and_b32 0xffffe000) for hi and subtracted in fp32: same precision class (hi truncated:
+// |lo| <= 2^-10 |x|), two instructions more.  VSP_SPLIT_FORM=0 builds that form (timing A/B only; it saturates).
+// (The operands come from compiler-generated vector instructions, never straight from an MFMA result: see the hazard
+// note in g16_common.h.)
+#ifndef VSP_SPLIT_FORM
+#define VSP_SPLIT_FORM 1
+#endif
+__device__ __forceinline__ void vsp_split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
+#if VSP_SPLIT_FORM == 0
+  const float h0 = __uint_as_float(__float_as_uint(x0) & 0xffffe000u), h1 = __uint_as_float(__float_as_uint(x1) & 0xffffe000u);
+  float l0, l1;
+  asm("v_sub_f32 %0, %1, %2" : "=v"(l0) : "v"(x0), "v"(h0));     // (plain f32 instructions: hipcc would SLP-pack them)
+  asm("v_sub_f32 %0, %1, %2" : "=v"(l1) : "v"(x1), "v"(h1));
+  hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h0, h1));
+  lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(l0, l1));
+#else
+  float l0, l1;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(x0), "v"(x1));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hi), "v"(x0));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hi), "v"(x1));
+  lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(l0, l1));
+#endif
+}
+#endif
 
 // ------------------------------------------------------------------------------------------
 // channels-last split-f16 vocoder conv (gen16.hip): x [B][T][Cin], out [B][T][Cout]
@@ -173,10 +211,13 @@ void pack_g16_weights(uint16_t* dst, int rows, int Cin, int K, const float* dens
 // mel[b][m][t] = log(max(sum_{f in [lo[m], hi[m])} basis[m][f] * spec[b][f][t], 1e-5))  (reference mel_processing.py:16-22, 73-82)
 hipError_t launch_spec_to_mel(const float* spec, const float* basis, const int* lo, const int* hi, float* mel, int B,
                               int n_freq, int n_mels, int T, hipStream_t s);
+// y = transpose(x) * scale (the generator's entry: the context's activation scale, model.h)
 hipError_t launch_transpose_ct(const float* x, long x_bs, long x_cs, float* y, long y_bs, int y_ts, int B, int C,
-                               int T, hipStream_t s);
+                               int T, hipStream_t s, float scale = 1.f);
+// o = tanh(unscale * conv(lrelu(x)));  flags != NULL: VSP_FLAG_NONFINITE_WAVE is raised there when a sum is inf / NaN
 hipError_t launch_conv_post_cl(const float* x, long x_bs, int x_ts, const float* w, int C, int K, float slope,
-                               float* o, long o_bs, int B, int T, hipStream_t s, const int* glen = nullptr, int grate = 0);
+                               float* o, long o_bs, int B, int T, hipStream_t s, const int* glen = nullptr, int grate = 0,
+                               float unscale = 1.f, unsigned* flags = nullptr);
 // Trimmed tails (round 5).  The generator's input behind an utterance's last frame is exactly zero (reference
 // models.py:720: z * x_mask), so its output there is a bias-driven signal that depends on the distance to the utterance's
 // end and to the tensor's end only: periodic in one frame once the receptive field away from both.
@@ -239,13 +280,13 @@ hipError_t launch_length_regulate(const float* x, long x_bs, long x_cs, const in
                                   long o_bs, long o_cs, int B, int C, int Tp, int Tf, hipStream_t s);
 // z_p = m_p + noise * exp(logs_p) * noise_scale ; x_mask[b][t] = t < len[b]
 hipError_t launch_reparam(const float* m_p, const float* logs_p, const float* noise, float noise_scale,
-                          float* z_p, long n, hipStream_t s, float* copy = nullptr);
+                          float* z_p, long n, hipStream_t s, float* copy = nullptr, unsigned* flags = nullptr);
 // out[i] = standard normal draw first + i of the Philox4x32-10 stream keyed by `seed` (misc.hip)
 hipError_t launch_randn(uint64_t seed, long first, long n, float* out, hipStream_t s);
 hipError_t launch_mask_u8(const int64_t* lengths, uint8_t* mask, int B, int T, hipStream_t s);
 // o[b][t] = tanh( sum_c sum_j w[c][j] * lrelu(x[b][c][t+j-pad], slope) )  (conv_post, no bias)
 hipError_t launch_conv_post(const float* x, long x_bs, long x_cs, const float* w, int C, int K, float slope,
-                            float* o, long o_bs, int B, int T, hipStream_t s);
+                            float* o, long o_bs, int B, int T, hipStream_t s, unsigned* flags = nullptr);
 hipError_t launch_copy3(const float* x, long x_bs, long x_cs, float* y, long y_bs, long y_cs, int B, int C,
                         int T, hipStream_t s);
 // x[b][c][t] = 0 for t >= lengths[b]

@@ -364,17 +364,20 @@ hipError_t launch_length_regulate(const float* x, long x_bs, long x_cs, const in
 // z_p = m_p + noise * exp(logs_p) * noise_scale  (reference models.py:718)
 __global__ void reparam_kernel(const float* __restrict__ m_p, const float* __restrict__ logs_p,
                                const float* __restrict__ noise, float noise_scale, float* __restrict__ z_p, long n,
-                               float* __restrict__ copy) {
+                               float* __restrict__ copy, unsigned* __restrict__ flags) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float nz = noise ? noise[i] : 0.f;
   const float v = m_p[i] + nz * expf(logs_p[i]) * noise_scale;
   z_p[i] = v;
   if (copy) copy[i] = v;        // (the tensor the inverse flow then transforms in place: saves a copy launch)
+  // the frame-rate stages behind m_p / logs_p (text encoder, frame prior network, projection) left the split-f16 range
+  // (conv_mfma.hip: an operand beyond +-65504 becomes inf) or the caller's noise is not finite: sticky flag, vsp_status
+  if (flags && !(fabsf(v) <= 3.0e38f)) atomicOr(flags, VSP_FLAG_NONFINITE_LATENT);
 }
 hipError_t launch_reparam(const float* m_p, const float* logs_p, const float* noise, float noise_scale, float* z_p,
-                          long n, hipStream_t s, float* copy) {
-  hipLaunchKernelGGL(reparam_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, m_p, logs_p, noise, noise_scale, z_p, n, copy);
+                          long n, hipStream_t s, float* copy, unsigned* flags) {
+  hipLaunchKernelGGL(reparam_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, m_p, logs_p, noise, noise_scale, z_p, n, copy, flags);
   return hipGetLastError();
 }
 
@@ -448,7 +451,8 @@ constexpr int CP_TILE = 512;
 constexpr int CP_MAXK = 8;
 __global__ void __launch_bounds__(128) conv_post_kernel(const float* __restrict__ x, long x_bs, long x_cs,
                                                         const float* __restrict__ w, int C, int K, float slope,
-                                                        float* __restrict__ o, long o_bs, int T) {
+                                                        float* __restrict__ o, long o_bs, int T,
+                                                        unsigned* __restrict__ flags) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int LW = CP_TILE + 8;
   float* xs = sm;            // [C][LW]
@@ -488,17 +492,20 @@ __global__ void __launch_bounds__(128) conv_post_kernel(const float* __restrict_
 #pragma unroll
   for (int n = 0; n < 4; ++n) {
     const int t = t0 + tl + n;
-    if (t < T) ob[t] = tanhf(acc[n]);
+    if (t < T) {
+      ob[t] = tanhf(acc[n]);
+      if (flags && !(fabsf(acc[n]) <= 3.0e38f)) atomicOr(flags, VSP_FLAG_NONFINITE_WAVE);
+    }
   }
 }
 hipError_t launch_conv_post(const float* x, long x_bs, long x_cs, const float* w, int C, int K, float slope,
-                            float* o, long o_bs, int B, int T, hipStream_t s) {
+                            float* o, long o_bs, int B, int T, hipStream_t s, unsigned* flags) {
   if (K > CP_MAXK || C > 32) return hipErrorInvalidValue;
   const size_t lds = ((size_t)C * (CP_TILE + 8) + (size_t)C * CP_MAXK) * sizeof(float);
   static std::atomic<uint64_t> attr_done{0};
   if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(conv_post_kernel), 140 * 1024, attr_done); e != hipSuccess) return e;
   hipLaunchKernelGGL(conv_post_kernel, dim3(cdiv(T, CP_TILE), B), dim3(128), lds, s, x, x_bs, x_cs, w, C, K, slope,
-                     o, o_bs, T);
+                     o, o_bs, T, flags);
   return hipGetLastError();
 }
 

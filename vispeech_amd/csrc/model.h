@@ -118,6 +118,15 @@ struct vsp_ctx {
   bool pair_ring = false;         // VSP_PAIR=ring: the LDS-ring pair kernel on the 32-channel stage instead of g16_rw
   bool chain_ring = false;        // VSP_CHAIN_RING=1: the LDS-ring chain kernel (g16_chain) instead of g16_rc
   bool rw64 = false;              // VSP_RW64=1: the 64-channel k3 pairs on g16_rw64 (register weights; measured slower: opt-in)
+  // Activation scale of the channels-last generator (round 6; VSP_ACT_SCALE_LOG2 = 0 .. 8, default 4): the fp32 activations
+  // between conv_pre and conv_post are carried * act_scale (a power of two: every layer in between is positively
+  // homogeneous -- leaky-relu, convolutions, sums -- once the packed biases carry the factor too, weights.cpp), so that the
+  // operand split's UNSCALED lo parts (g16_common.h) fall under the f16 subnormal granularity 2^-24 only for
+  // |x| < 2^-4 / act_scale: the level below which the waveform leaves the 1e-4 gate moves from -68 to about -92 dBFS; the
+  // price is the upper end, |x| < 65504 / act_scale (beyond it: inf, flagged -- vsp_status).  Part of the arena's hash.
+  float act_scale = 16.f;
+  unsigned* flags_host = nullptr;   // pinned + mapped status word the kernels raise VSP_FLAG_* in (vsp_status)
+  unsigned* flags_dev = nullptr;    // its device address
   bool trim_tails = true;         // ragged batches: the generator runs each utterance to length + 2 halo + 1 frames and fills the
                                   // padded tail from the steady state (VSP_TRIM_TAILS=0: to the padded length; bit-identical)
   // round 5, measured and NOT adopted (profiles/r05_resblock_chains_on_side_streams.txt): the ResBlocks of a generator stage
@@ -134,6 +143,12 @@ struct vsp_ctx {
   int fl_cap = 0, fl_n = 0;
   hipEvent_t fl_ev = nullptr;
   const int64_t* fl_src = nullptr;   // device tensor the pending early copy was taken from (nullptr: none pending)
+  // what the last vsp_frame_lengths_host returned, valid until the next vsp_encode / vsp_infer: lets vsp_decode see on
+  // the HOST that no utterance of the batch can be trimmed (a uniform batch, one long utterance) and run the generator
+  // without per-utterance extents -- the only use: a stale match can only turn trimming off or on, both of which give
+  // the reference's output
+  std::vector<int64_t> fl_known;
+  const int64_t* fl_known_src = nullptr;
   hipStream_t side[2] = {nullptr, nullptr};
   std::vector<hipEvent_t> sync_ev;
   int64_t noise_first = 0;        // stream index of element 0 of a library-drawn noise tensor (vsp_set_noise_offset)
@@ -154,11 +169,13 @@ struct vsp_ctx {
   std::vector<int> ev_cls;           // class of event pair i (events 2i, 2i+1)
   std::vector<int> ev_fam;           // kernel family of event pair i (VSP_FAM_* in vispeech_hip.h)
   std::vector<double> ev_flops, ev_bytes;   // algorithmic work of the launch of event pair i
+  std::vector<double> ev_moved;             // bytes that launch must MOVE through HBM as fused (each operand once)
   size_t ev_used = 0;
   int64_t prof_launches[VSP_PROF_CLASSES] = {};
   double prof_flops[VSP_PROF_CLASSES] = {};
   double prof_bytes[VSP_PROF_CLASSES] = {};       // input once + output once per convolution
   double prof_bytes_ext[VSP_PROF_CLASSES] = {};   // the same plus residual / accumulate operand reads
+  double prof_bytes_moved[VSP_PROF_CLASSES] = {}; // what the launches move as FUSED: input, output, residual, previous sum once each
 
   int fail(int code, const char* fmt, ...) {
     char buf[512];

@@ -415,7 +415,8 @@ struct Filler {
     if (ctx->gen_mode != 0) check_f16_range(dense);       // (VSP_GENERATOR=f32 never multiplies this image)
     // [phase][co][ci][tap] is [row = phase * Cout + co][ci][tap]: the stacked-phase form gen16.hip multiplies
     pack_g16_weights(reinterpret_cast<uint16_t*>(arena.data() + c.wg), c.phases * c.Cout, c.Cin, c.K, dense.data());
-    for (int co = 0; co < c.Cout; ++co) arena[c.b + co] = b(co) * G16_WSCALE;   // (kernels.h: the bias rides in the scaled accumulator)
+    // (kernels.h: the bias rides in the scaled accumulator; model.h: ... of activations that are carried * act_scale)
+    for (int co = 0; co < c.Cout; ++co) arena[c.b + co] = b(co) * G16_WSCALE * ctx->act_scale;
   }
   void clconv_plain(const ClConv& c, const std::string& wname, const std::string& bname) {
     const HostTensor* W = get(wname);

@@ -176,7 +176,29 @@ class Engine:
         with torch.cuda.device(self.device):
             rc = self.lib.vsp_frame_lengths_host(self.ctx, self._stream(), B, _ptr(frame_lengths), host, C.byref(mx))
         _lib.check(rc, self.ctx, "vsp_frame_lengths_host")
+        self.check_numerics(sync=False)       # (free: a pinned word; reports what has completed, e.g. the previous call)
         return list(host), int(mx.value)
+
+    # ------------------------------------------------------------------ numeric-range status (vsp_status)
+    def status(self, clear: bool = False) -> int:
+        """The context's sticky VSP_FLAG_* word (no synchronisation: launches that have completed)."""
+        flags = C.c_uint(0)
+        _lib.check(self.lib.vsp_status(self.ctx, C.byref(flags), int(clear)), self.ctx, "vsp_status")
+        return int(flags.value)
+
+    def check_numerics(self, sync: bool = True) -> None:
+        """Raise ``VspError`` if a kernel has reported non-finite values since the last check -- an activation left the
+        range the split-f16 matrix kernels represent (include/vispeech_hip.h, vsp_status) or an input was not finite.
+        ``sync=True`` waits for the device first, so that the answer covers everything enqueued so far."""
+        if sync:
+            torch.cuda.synchronize(self.device)
+        f = self.status(clear=True)
+        if f:
+            what = [n for b, n in ((_lib.FLAG_NONFINITE_LATENT, "z_p (phoneme- / frame-rate stages)"),
+                                   (_lib.FLAG_NONFINITE_WAVE, "the waveform (flow / generator)")) if f & b]
+            raise _lib.VspError("non-finite values in " + " and ".join(what) + ": an activation beyond the split-f16 range "
+                                "(|x| > 65504; inside the generator 65504 / 2^VSP_ACT_SCALE_LOG2) or a non-finite input; "
+                                "VSP_GENERATOR=f32 / VSP_FRAME=f32 select the f32 matrix kernels, which have no such limit")
 
     def decode_buffers(self, B: int, Tp: int, Tf: int, max_len: Optional[int] = None):
         """Output tensors and workspace of ``decode`` for a padded frame count ``Tf``.  A caller that knows ``Tf`` before
@@ -454,6 +476,15 @@ class Engine:
         """Frames of context the streamed vocoder adds on each side (``vsp_generator_halo_frames``)."""
         return int(self.lib.vsp_generator_halo_frames(self.ctx))
 
+    def generator_frame_dependence(self):
+        """(back, fwd): output frame F of the vocoder depends on input frames [F - back, F + fwd], sample-exact from the
+        configuration (``vsp_generator_frame_dependence``; 13 / 13 for configs/config.json) -- what the trimmed tails of a
+        ragged batch rest on: an utterance of L frames is computed to min(T, L + back + 1 + fwd) frames."""
+        b, f = C.c_int(), C.c_int()
+        _lib.check(self.lib.vsp_generator_frame_dependence(self.ctx, C.byref(b), C.byref(f)), self.ctx,
+                   "vsp_generator_frame_dependence")
+        return int(b.value), int(f.value)
+
     def generator_stream(self, z, g, chunk_frames: int = 256):
         """Streamed vocoder (BASELINE config 5): yields the waveform of ``z`` [B][C][T] chunk by chunk
         ([B,1,512*n] tensors) so that the first audio is available after one chunk instead of after
@@ -478,25 +509,26 @@ class Engine:
         _lib.check(self.lib.vsp_profile_enable(self.ctx, int(on)), self.ctx, "vsp_profile_enable")
 
     def profile_read(self, reset: bool = True, cls: int = _lib.PROF_GENERATOR):
-        """(launches, ms, algorithmic FLOPs, SURVEY-8d bytes, bytes incl. residual / accumulate reads) of one class."""
-        n, ms, fl, by, bx = C.c_int64(), C.c_double(), C.c_double(), C.c_double(), C.c_double()
+        """(launches, ms, algorithmic FLOPs, SURVEY-8d bytes, bytes incl. residual / accumulate reads, bytes the launches
+        move as fused) of one class."""
+        n, ms, fl, by, bx, bm = C.c_int64(), C.c_double(), C.c_double(), C.c_double(), C.c_double(), C.c_double()
         _lib.check(self.lib.vsp_profile_read_class(self.ctx, int(cls), C.byref(n), C.byref(ms), C.byref(fl), C.byref(by),
-                                                   C.byref(bx), int(reset)), self.ctx, "vsp_profile_read_class")
-        return int(n.value), float(ms.value), float(fl.value), float(by.value), float(bx.value)
+                                                   C.byref(bx), C.byref(bm), int(reset)), self.ctx, "vsp_profile_read_class")
+        return int(n.value), float(ms.value), float(fl.value), float(by.value), float(bx.value), float(bm.value)
 
 
     _FAMILY_KINDS = {0: "other", 1: "conv", 2: "ups", 3: "pair", 4: "chain", 5: "pre"}
 
     def profile_read_families(self, cls: int = _lib.PROF_GENERATOR, max_families: int = 64):
         """Per kernel family of one class since the last reset (call BEFORE profile_read(reset=True)):
-        [{kind, channels, launches, ms, flops, bytes}], largest total time first."""
+        [{kind, channels, launches, ms, flops, bytes, moved}], largest total time first."""
         m = int(max_families)
         fam, n = (C.c_int * m)(), (C.c_int64 * m)()
-        ms, fl, by = (C.c_double * m)(), (C.c_double * m)(), (C.c_double * m)()
-        k = self.lib.vsp_profile_read_families(self.ctx, int(cls), m, fam, n, ms, fl, by)
+        ms, fl, by, bm = (C.c_double * m)(), (C.c_double * m)(), (C.c_double * m)(), (C.c_double * m)()
+        k = self.lib.vsp_profile_read_families(self.ctx, int(cls), m, fam, n, ms, fl, by, bm)
         _lib.check(min(k, 0), self.ctx, "vsp_profile_read_families")
         out = [dict(kind=self._FAMILY_KINDS.get(fam[i] & 7, "other"), channels=32 << (fam[i] >> 3), launches=int(n[i]),
-                    ms=float(ms[i]), flops=float(fl[i]), bytes=float(by[i])) for i in range(k)]
+                    ms=float(ms[i]), flops=float(fl[i]), bytes=float(by[i]), moved=float(bm[i])) for i in range(k)]
         return sorted(out, key=lambda d: -d["ms"])
 
 

@@ -70,7 +70,20 @@ class SynthesizerTrn:
         return self.to(f"cuda:{0 if device is None else device}")
 
     def state_dict(self):
-        return {k: torch.from_numpy(v.copy()) for k, v in self._state.items()}
+        """Every tensor of the reference's 753-key schema, in the reference's order: the loaded value where one has been
+        loaded, zeros of the schema's shape otherwise -- so that the reference's own loader (utils.py:29-46), which
+        iterates ``model.state_dict()`` BEFORE the first load and keeps the model's value for keys the checkpoint
+        lacks, runs against this class as written (inference.py:36).  (The reference keeps its random init there; this
+        class has no init: a key the checkpoint lacks loads as zeros.)"""
+        from collections import OrderedDict
+        out = OrderedDict()
+        for k, shape in state_dict_schema(self.dims).items():
+            v = self._state.get(k)
+            out[k] = torch.from_numpy(v.copy()) if v is not None else torch.zeros(shape, dtype=torch.float32)
+        for k, v in self._state.items():
+            if k not in out:
+                out[k] = torch.from_numpy(v.copy())
+        return out
 
     def load_state_dict(self, state_dict: Mapping[str, "torch.Tensor | np.ndarray"], strict: bool = True):
         """Accepts a reference ``net_g.state_dict()`` / ``checkpoint['model']`` unchanged."""

@@ -102,7 +102,9 @@ class SynthesisService:
         try:
             o, frames = self._infer(batch, noise)
             hop = self.net.dims.total_upsample
-            return pcm16(o[utterance, 0, : int(frames[utterance]) * hop])
+            pcm = pcm16(o[utterance, 0, : int(frames[utterance]) * hop])      # (device -> host: the stream has drained)
+            self._check_numerics()
+            return pcm
         finally:
             self.release()
 
@@ -142,10 +144,18 @@ class SynthesisService:
             if left <= 0:
                 break
             piece = pcm16(o[utterance, 0, : min(left, o.shape[2])])
+            self._check_numerics()
             left -= piece.size
             yield piece.tobytes()
 
     # ------------------------------------------------------------------ helpers
+    def _check_numerics(self) -> None:
+        """After a device -> host copy: raise if a kernel reported values outside the range the split-f16 matrix kernels
+        represent (Engine.check_numerics; the audio just copied would be inf / NaN garbage)."""
+        eng = getattr(self.net, "_engine", None)
+        if eng is not None and hasattr(eng, "check_numerics"):
+            eng.check_numerics(sync=False)
+
     def _controls(self, batch):
         return {k: batch.get(k) for k in ("duration", "f0", "energy")}
 
