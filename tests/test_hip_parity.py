@@ -506,6 +506,33 @@ def test_alternative_kernel_paths_match_golden(dims, weights, golden_dir, monkey
         assert rel_err(to_np(out[2][2]), g["m_p"]) <= STAGE_TOL, case
 
 
+@pytest.mark.parametrize("env", [{"VSP_COLS": "0"}, {"VSP_COLS_MIN_BLOCKS": "0"}, {"VSP_COLS_MIN_BLOCKS": "0", "VSP_COLS_BLOCKS": "100000"}])
+def test_column_tile_kernels_and_row_tiled_kernels_both_match_golden(net, dims, weights, golden_dir, monkeypatch, env):
+    """Round 6's column-tile kernels (conv_cols.hip: mid-size 1x1 convolutions; conv_o + LayerNorm and q | k | v +
+    operand packing in one launch each) serve grids of 32 .. 256 column tiles by default (the per-rank slices of a sharded
+    batch; the full-size tests of tests/test_baseline_configs.py run the two fused launches).  The goldens are a few
+    column tiles, so here the selections are forced: VSP_COLS=0 (row-tiled kernels + separate pack / LayerNorm launches
+    everywhere: round 5's path), VSP_COLS_MIN_BLOCKS=0 (column tiles from the first tile on), and with
+    VSP_COLS_BLOCKS=100000 at every size -- each against the reference goldens, and against the default selection
+    within the stage tolerance (another summation order, not the same bits)."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    from vispeech_amd import config as vcfg
+    from vispeech_amd.models import SynthesizerTrn
+    args, kwargs = vcfg.synthesizer_args(vcfg.default_hparams())
+    m = SynthesizerTrn(*args, **kwargs).eval()
+    m.load_state_dict(weights, strict=True)
+    for case in ("ragged_predictors", "ragged_controls", "evaluate_caller"):
+        g = golden(golden_dir, case)
+        out = run_case(m, g)
+        ref = run_case(net, g)
+        np.testing.assert_array_equal(to_np(out[3]).reshape(g["duration"].shape), g["duration"])
+        assert rel_err(to_np(out[0]), g["o"]) <= WAVE_TOL, case
+        for name, i in (("z", 0), ("z_p", 1), ("m_p", 2), ("logs_p", 3)):
+            assert rel_err(to_np(out[2][i]), g[name]) <= STAGE_TOL, (case, name)
+            assert rel_err(to_np(out[2][i]), to_np(ref[2][i])) <= STAGE_TOL, (case, name)
+
+
 def test_single_call_infer_matches_three_call_path(net, golden_dir):
     """vsp_infer (one call, caller-supplied frame padding, no host synchronisation) == vsp_encode +
     vsp_frame_lengths_host + vsp_decode, bit for bit, and both match the reference golden."""

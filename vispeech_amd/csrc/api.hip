@@ -89,6 +89,9 @@ struct Run {
     a.alpha = 1.f; a.div = 1.f;
     a.ups_s = L.ups_s; a.ups_p = L.ups_p;
     a.f16s = L.f16s ? 1 : 0;
+    a.wg = (L.has_wg && ctx->cols) ? reinterpret_cast<const uint16_t*>(A(L.wg)) : nullptr;
+    a.wg_max_blocks = ctx->cols_blocks;
+    a.wg_min_blocks = ctx->cols_min_blocks;
     return a;
   }
   // event pair around one launch of a profiled class; end() books the launch's algorithmic work
@@ -260,17 +263,36 @@ void run_encoder_masked(Run& r, const EncoderW& E, int B, int T, T3 x_in, const 
     }
     return;
   }
+  // round 6, the column-tile kernels (conv_cols.h): the projections write the packed attention operands themselves
+  // (no [B][3h][T] tensor, no pack launch) and conv_o normalises in its own launch (no LayerNorm launch): 8 -> 6 launches
+  // per layer.  VSP_COLS=0: the separate launches (second implementation, tests/test_hip_parity.py).
+  // (not for a handful of column tiles -- one utterance --: a column-tile block is one chain of round trips of 10+ us, the
+  // row-tiled kernels' blocks are shorter than the launch they save: measured 3.12 against 3.14 ms for one utterance)
+  const long col_tiles = (long)B * ((T + 63) / 64);
+  const bool cols_size = col_tiles >= r.ctx->cols_min_blocks;
+  const bool fuse_qkv = r.ctx->cols && cols_size && r.ctx->att_f16s && r.ctx->frame_f16s && E.layers[0].qkv.has_wg &&
+                        E.layers[0].qkv.Cin == h && attn_qkv_pack_supported(h, c.n_heads);
+  const bool fuse_ln = r.ctx->cols && cols_size && r.ctx->frame_f16s && E.layers[0].o.has_wg && h == 192;
   for (size_t i = 0; i < E.layers.size(); ++i) {
     const EncLayer& L = E.layers[i];
     const T3 Xi = i == 0 ? x_in : X;            // this layer's input
     const bool last = i + 1 == E.layers.size();
     ConvArgs a = r.args(L.qkv, Xi, QKV, T, T);
     a.lengths = lengths; a.in_mask = 1;  // x * x_mask feeds the attention (attentions.py:38)
-    r.conv(a, B);
+    if (!fuse_qkv) r.conv(a, B);
+    else if (!r.dry() && r.ok()) {
+      const bool prof = r.prof_begin(VSP_PROF_FRAME);
+      r.chk(launch_attn_qkv_pack_f16s(Xi.p, Xi.bs, Xi.cs, a.wg, a.bias, lengths, B, h, c.n_heads, T, AP, r.s), "q | k | v + pack");
+      if (prof) {
+        const double in_el = (double)T * h, out_el = (double)T * 3 * h;
+        r.prof_end(VSP_PROF_FRAME, 2.0 * 3 * h * h * (double)T * B, 4.0 * B * (in_el + out_el), 4.0 * B * (in_el + out_el),
+                   4.0 * B * (in_el + out_el));
+      }
+    }
     if (!r.dry() && r.ok()) {
       const bool prof = r.prof_begin(VSP_PROF_ATTENTION);
       if (r.ctx->att_f16s)
-        r.chk(launch_attention_f16s(QKV.p, QKV.bs, QKV.cs, r.A(L.ek), r.A(L.ev), lengths, AT.p, AT.bs, AT.cs, B, h,
+        r.chk(launch_attention_f16s(fuse_qkv ? nullptr : QKV.p, QKV.bs, QKV.cs, r.A(L.ek), r.A(L.ev), lengths, AT.p, AT.bs, AT.cs, B, h,
                                     c.n_heads, T, c.window_size, AP, r.s), "attention (split f16)");
       else
         r.chk(launch_attention(QKV.p, QKV.bs, QKV.cs, r.A(L.ek), r.A(L.ev), lengths, AT.p, AT.bs, AT.cs, B, h,
@@ -279,11 +301,24 @@ void run_encoder_masked(Run& r, const EncoderW& E, int B, int T, T3 x_in, const 
       if (prof) r.prof_end(VSP_PROF_ATTENTION, (double)B * (4.0 * h * (double)T * T + 4.0 * h * (double)T * (2 * c.window_size + 1)),
                            4.0 * B * 4.0 * h * (double)T, 4.0 * B * 4.0 * h * (double)T, 4.0 * B * 4.0 * h * (double)T);
     }
-    // S = x + conv_o(att)
+    // S = x + conv_o(att);  X = LayerNorm(S)
     a = r.args(L.o, AT, S, T, T);
     a.res = Xi.p; a.r_bs = Xi.bs; a.r_cs = Xi.cs;
-    r.conv(a, B);
-    r.ln(S, T3{}, L.g1, L.b1, X, B, h, T);
+    if (fuse_ln && a.wg) {
+      // one launch: the block holds every channel of its columns (Xi may be X: a block reads and writes its own columns only)
+      a.out = X.p; a.o_bs = X.bs; a.o_cs = X.cs;
+      if (!r.dry() && r.ok()) {
+        const bool prof = r.prof_begin(VSP_PROF_FRAME);
+        r.chk(launch_conv_cols(a, B, r.s, r.A(L.g1), r.A(L.b1)), "conv_o + LayerNorm");
+        if (prof) {
+          const double el = (double)T * h;
+          r.prof_end(VSP_PROF_FRAME, 2.0 * h * h * (double)T * B, 4.0 * B * 2.0 * el, 4.0 * B * 3.0 * el, 4.0 * B * 3.0 * el);
+        }
+      }
+    } else {
+      r.conv(a, B);
+      r.ln(S, T3{}, L.g1, L.b1, X, B, h, T);
+    }
     // FFN (attentions.py:277-285)
     a = r.args(L.f1, X, FF, T, T);
     a.lengths = lengths; a.in_mask = 1; a.act = 1;
@@ -768,6 +803,9 @@ int vsp_create(const vsp_config* cfg, int device, vsp_ctx** out) {
   if (const char* e = getenv("VSP_CHAIN")) ctx->chain_mask = atoi(e);
   if (const char* e = getenv("VSP_RW64")) ctx->rw64 = atoi(e) != 0;               // 1: g16_rw64 for the 64-channel k3 pairs (opt-in)
   if (const char* e = getenv("VSP_TRIM_TAILS")) ctx->trim_tails = atoi(e) != 0;   // 0: every utterance runs to the padded length
+  if (const char* e = getenv("VSP_COLS")) ctx->cols = atoi(e) != 0;               // 0: no column-tile kernels (second implementation)
+  if (const char* e = getenv("VSP_COLS_BLOCKS")) ctx->cols_blocks = atol(e);      // size limits of launch_conv's routing to them
+  if (const char* e = getenv("VSP_COLS_MIN_BLOCKS")) ctx->cols_min_blocks = atol(e);
   if (const char* e = getenv("VSP_ACT_SCALE_LOG2")) {                             // model.h: the generator's activation scale
     const int l = atoi(e);
     ctx->act_scale = std::ldexp(1.f, l < 0 ? 0 : l > 8 ? 8 : l);

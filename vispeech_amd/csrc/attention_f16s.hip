@@ -21,6 +21,7 @@
 // Mask semantics unchanged: -1e4 (times log2 e in the 2^x domain) for masked pairs, so a fully masked query row
 // gives the uniform average the reference gives; keys beyond T get -inf.
 #include "kernels.h"
+#include "conv_cols.h"
 
 #include <cstdlib>
 #include <type_traits>
@@ -28,9 +29,6 @@
 
 namespace vsp {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int AF_RS = 17;             // row stride of the per-query band tables (2w+1 <= 16)
 constexpr float AF_QS = 128.f;        // operand scales (powers of two): q, k, v, p
@@ -39,8 +37,6 @@ constexpr float AF_VS = 16.f;
 constexpr float AF_PEXP = 14.f;       // p is carried as p * 2^14 (<= 16384: fits f16, its lo part stays normal)
 constexpr float AF_LOG2E = 1.4426950408889634f;
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 // x -> hi = f16(x), lo = f16(x - hi), two values at a time.  The empty asm pins the ROUNDED hi that is stored as THE
 // value the residual is taken against: left to itself hipcc re-derived hi for the subtraction by another conversion
@@ -134,6 +130,80 @@ __global__ void __launch_bounds__(256) attn_pack_f16s(const float* __restrict__ 
         *reinterpret_cast<f16x8*>(dst + (blk * 64 + lane) * 8) = vh;
         *reinterpret_cast<f16x8*>(dst + ((blk + 1) * 64 + lane) * 8) = vl;
       }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The attention projections and the packing in ONE launch (round 6): conv_q | conv_k | conv_v (reference
+// attentions.py:138-146: 1x1 convolutions of x * x_mask) on the column-tile form of conv_cols.h -- a block computes all H
+// rows of q, k or v for 64 time steps into an LDS tile -- and the tile goes straight into the packed operand images
+// (attn_pack_f16s's code, reading the LDS tile instead of the fp32 tensor): the [B][3H][T] tensor never exists, one launch
+// and one HBM round trip less per encoder layer.  grid = (T / 64, 3, B); wg = pack_g16_weights of the 3H x H projection.
+template <int DK, int NH>
+__global__ void __launch_bounds__(256, 1) attn_qkv_pack_f16s(const float* __restrict__ x, long x_bs, long x_cs,
+                                                            const uint16_t* __restrict__ wg, const float* __restrict__ bias,
+                                                            const int64_t* __restrict__ lengths, int T,
+                                                            _Float16* __restrict__ Qp, _Float16* __restrict__ Kp,
+                                                            _Float16* __restrict__ Vp) {
+  constexpr int H = DK * NH, NC = DK / 32, ND = DK / 16, MTB = H / 16, MW = (MTB + 3) / 4;
+  extern __shared__ __attribute__((aligned(16))) char qp_smem[];
+  char* const img = qp_smem;
+  float* const tile = reinterpret_cast<float*>(qp_smem + cc_image_bytes(H));
+  const int b = blockIdx.z, which = blockIdx.y, t0 = blockIdx.x * 64, tid = threadIdx.x;
+  int len = T;
+  if (lengths) { const long l = lengths[b]; len = l < 0 ? 0 : (l < T ? (int)l : T); }
+  CcWeights<MW, H> W;
+  cc_load_weights<MW, H>(W, wg, 3 * MTB, which * MTB, MTB);
+  cc_stage_x<H>(x + (size_t)b * x_bs, x_cs, t0, len, img);
+  cc_contract<MW, H>(W, MTB, img, tile);
+  // + bias; columns beyond T are zero in the images (attn_pack_f16s: "values beyond T are zero")
+  for (int idx = tid; idx < H * 64; idx += 256) {
+    const int d = idx >> 6, tl = idx & 63;
+    tile[d * CC_TS + tl] = t0 + tl < T ? tile[d * CC_TS + tl] + bias[which * H + d] : 0.f;
+  }
+  __syncthreads();
+  const size_t tpad = (size_t)gridDim.x * 64;
+  const float qscale = AF_QS * AF_LOG2E / sqrtf((float)DK);
+  const float sc = which == 0 ? qscale : (which == 1 ? AF_KS : AF_VS);
+  if (which < 2) {
+    for (int u = tid; u < NH * 64 * NC * 4; u += 256) {
+      const int hd = u / (64 * NC * 4), uu = u % (64 * NC * 4);
+      const int tl = uu & 63, c = (uu >> 6) % NC, q4 = (uu >> 6) / NC;
+      const float* th = tile + (size_t)hd * DK * CC_TS;
+      _Float16* dst = (which == 0 ? Qp : Kp) + ((size_t)b * NH + hd) * tpad * DK * 2;
+      f16x8 vh, vl;
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        f16x2 h2, l2;
+        af_split2(f32x2{th[(c * 32 + q4 * 8 + j) * CC_TS + tl] * sc, th[(c * 32 + q4 * 8 + j + 1) * CC_TS + tl] * sc}, h2, l2);
+        vh[j] = h2.x; vh[j + 1] = h2.y;
+        vl[j] = l2.x; vl[j + 1] = l2.y;
+      }
+      const size_t blk = ((size_t)((t0 + tl) >> 4) * NC + c) * 2;
+      const int lane = (tl & 15) + 16 * q4;
+      *reinterpret_cast<f16x8*>(dst + (blk * 64 + lane) * 8) = vh;
+      *reinterpret_cast<f16x8*>(dst + ((blk + 1) * 64 + lane) * 8) = vl;
+    }
+  } else {
+    for (int u = tid; u < NH * DK * 2 * 4; u += 256) {
+      const int hd = u / (DK * 2 * 4), uu = u % (DK * 2 * 4);
+      const int d = uu % DK, g = (uu / DK) & 1, q4 = uu / (2 * DK);
+      const float* th = tile + (size_t)hd * DK * CC_TS;
+      _Float16* dst = Vp + ((size_t)b * NH + hd) * tpad * DK * 2;
+      f16x8 vh, vl;
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        const int key = g * 32 + (j < 4 ? 4 * q4 + j : 16 + 4 * q4 + (j - 4));     // (key + 1 for element j + 1)
+        f16x2 h2, l2;
+        af_split2(f32x2{th[d * CC_TS + key] * sc, th[d * CC_TS + key + 1] * sc}, h2, l2);
+        vh[j] = h2.x; vh[j + 1] = h2.y;
+        vl[j] = l2.x; vl[j + 1] = l2.y;
+      }
+      const size_t blk = ((size_t)((t0 >> 5) + g) * ND + (d >> 4)) * 2;
+      const int lane = (d & 15) + 16 * q4;
+      *reinterpret_cast<f16x8*>(dst + (blk * 64 + lane) * 8) = vh;
+      *reinterpret_cast<f16x8*>(dst + ((blk + 1) * 64 + lane) * 8) = vl;
     }
   }
 }
@@ -459,6 +529,7 @@ static void launch_attn_f16s(const float* qkv, long qkv_bs, long qkv_cs, const _
 }
 
 // workspace: 3 * attn_pack_bytes(B, n_heads, dk, T), 256-byte aligned
+// qkv == NULL: the images in `workspace` are already packed (launch_attn_qkv_pack_f16s)
 hipError_t launch_attention_f16s(const float* qkv, long qkv_bs, long qkv_cs, const float* emb_k, const float* emb_v,
                                  const int64_t* lengths, float* out, long o_bs, long o_cs, int B, int H, int n_heads, int T,
                                  int window, void* workspace, hipStream_t s) {
@@ -474,7 +545,7 @@ hipError_t launch_attention_f16s(const float* qkv, long qkv_bs, long qkv_cs, con
   // blocks with two key-tile streams otherwise
   const bool small = (long)((T + 127) / 128) * n_heads * B < 512;
 #define VSP_ATTF(DKV)                                                                                                   \
-  hipLaunchKernelGGL((attn_pack_f16s<DKV>), pgrid, dim3(256), 0, s, qkv, qkv_bs, qkv_cs, H, T, Qp, Kp, Vp);             \
+  if (qkv) hipLaunchKernelGGL((attn_pack_f16s<DKV>), pgrid, dim3(256), 0, s, qkv, qkv_bs, qkv_cs, H, T, Qp, Kp, Vp);    \
   if (small) launch_attn_f16s<DKV, 4, 1, 2>(qkv, qkv_bs, qkv_cs, Qp, Kp, Vp, emb_k, emb_v, lengths, out, o_bs, o_cs, B, H, n_heads, T, window, s); \
   else launch_attn_f16s<DKV, 8, 1, 1>(qkv, qkv_bs, qkv_cs, Qp, Kp, Vp, emb_k, emb_v, lengths, out, o_bs, o_cs, B, H, n_heads, T, window, s)
   if (dk == 96) { VSP_ATTF(96); }
@@ -482,6 +553,32 @@ hipError_t launch_attention_f16s(const float* qkv, long qkv_bs, long qkv_cs, con
   else if (dk == 32) { VSP_ATTF(32); }
   else return hipErrorInvalidValue;
 #undef VSP_ATTF
+  return hipGetLastError();
+}
+
+
+// the projections + packing launch (attn_qkv_pack_f16s): x [B][H][T], wg / bias of the stacked 3H x H projection
+bool attn_qkv_pack_supported(int H, int n_heads) { return n_heads == 2 && (H == 192 || H == 128 || H == 64); }
+hipError_t launch_attn_qkv_pack_f16s(const float* x, long x_bs, long x_cs, const uint16_t* wg, const float* bias,
+                                     const int64_t* lengths, int B, int H, int n_heads, int T, void* workspace, hipStream_t s) {
+  if (!attn_qkv_pack_supported(H, n_heads) || !wg || !bias || !workspace || B <= 0 || T <= 0) return hipErrorInvalidValue;
+  const int dk = H / n_heads;
+  const size_t one = attn_pack_bytes(B, n_heads, dk, T);
+  _Float16* Qp = static_cast<_Float16*>(workspace);
+  _Float16* Kp = reinterpret_cast<_Float16*>(static_cast<char*>(workspace) + one);
+  _Float16* Vp = reinterpret_cast<_Float16*>(static_cast<char*>(workspace) + 2 * one);
+  const dim3 grid((T + 63) / 64, 3, B);
+  const int lds = cc_image_bytes(H) + H * CC_TS * 4;
+#define VSP_QKVP(DKV)                                                                                                    \
+  {                                                                                                                      \
+    static std::atomic<uint64_t> attr_done{0};                                                                           \
+    if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(attn_qkv_pack_f16s<DKV, 2>), lds, attr_done); e != hipSuccess) return e; \
+    hipLaunchKernelGGL((attn_qkv_pack_f16s<DKV, 2>), grid, dim3(256), lds, s, x, x_bs, x_cs, wg, bias, lengths, T, Qp, Kp, Vp); \
+  }
+  if (dk == 96) VSP_QKVP(96)
+  else if (dk == 64) VSP_QKVP(64)
+  else VSP_QKVP(32)
+#undef VSP_QKVP
   return hipGetLastError();
 }
 

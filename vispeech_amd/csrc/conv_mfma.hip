@@ -1746,6 +1746,11 @@ hipError_t launch_conv(const ConvArgs& a, int B, hipStream_t s) {
 #endif
   if (ring && a.f16s) {
     if (a.ups_s > 0) return hipErrorInvalidValue;
+    // small grids: a 1x1 convolution whose weights have the column-tile image runs every row of a 64-column tile in one
+    // block (conv_cols.hip) -- the row-tiled kernels below are 3-9 blocks per column tile, each a chain of window round trips
+    // (a few blocks -- one utterance -- keep the row-tiled kernels: a column-tile block is one chain of round trips of ~10 us)
+    if (a.wg && conv_cols_supported(a) && (long)B * ((a.Nq + 63) / 64) <= a.wg_max_blocks &&
+        (long)B * ((a.Nq + 63) / 64) >= a.wg_min_blocks) return launch_conv_cols(a, B, s);
     // one time step, plain epilogue: the cond(g) projections
     if (a.K == 1 && a.T_in == 1 && a.Nq == 1 && a.Cin <= 2048 && a.act == 0 && !a.res && !a.cond && !a.in_mask && !a.in_act &&
         !a.mask_pre && !a.mask_post && !a.acc_prev && !a.split_row && a.alpha == 1.f && a.div == 1.f) {

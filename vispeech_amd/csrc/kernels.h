@@ -59,10 +59,19 @@ struct ConvArgs {
   // below it keep the epilogue above
   int split_row; float* out2; long o2_bs, o2_cs; int acc_prev2;
   int mask_post2;             // ... except this mask on the second destination (the two halves of one projection)
+  // round 6: the same weights in 16x16x32 A-fragment order (pack_g16_weights, K = 1) for the column-tile form
+  // (conv_cols.hip) of small-grid 1x1 convolutions; NULL = this convolution has no such image
+  const uint16_t* wg;
+  long wg_min_blocks, wg_max_blocks;   // launch_conv takes the column-tile kernel for this range of 64-column tiles (B * ceil(Nq / 64))
 };
 
 // the tile shape is chosen from M and Nq
 hipError_t launch_conv(const ConvArgs& a, int B, hipStream_t s);
+// Column-tile form of a 1x1 convolution (conv_cols.hip): every output row of a 64-column tile in ONE block.
+// ln_gamma / ln_beta != NULL: out = LayerNorm_channels(conv + bias + res) * gamma + beta (M = Cin = 192, no masks).
+bool conv_cols_supported(const ConvArgs& a);
+hipError_t launch_conv_cols(const ConvArgs& a, int B, hipStream_t s, const float* ln_gamma = nullptr,
+                            const float* ln_beta = nullptr);
 size_t packed_conv_floats(int M, int Cin, int K);
 // W(row, ci, tap) accessor -> packed buffer (host).  dst has packed_conv_floats(M,Cin,K) floats.
 void pack_conv_weights(float* dst, int M, int Cin, int K, const float* dense /* [M][Cin][K] */);
@@ -242,6 +251,11 @@ size_t attn_pack_bytes(int B, int n_heads, int DK, int T);
 hipError_t launch_attention_f16s(const float* qkv, long qkv_bs, long qkv_cs, const float* emb_k, const float* emb_v,
                                  const int64_t* lengths, float* out, long o_bs, long o_cs, int B, int H, int n_heads, int T,
                                  int window, void* workspace, hipStream_t s);
+// conv_q | conv_k | conv_v of x * x_mask AND the packing of their results in one launch: fills `workspace` with the images
+// launch_attention_f16s(qkv = NULL, ...) then consumes.  wg: pack_g16_weights of the stacked [3H][H] projection.
+bool attn_qkv_pack_supported(int H, int n_heads);
+hipError_t launch_attn_qkv_pack_f16s(const float* x, long x_bs, long x_cs, const uint16_t* wg, const float* bias,
+                                     const int64_t* lengths, int B, int H, int n_heads, int T, void* workspace, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------
 // small kernels (misc.hip)

@@ -26,6 +26,10 @@ struct Conv {
   size_t w = 0;
   long b = -1;
   bool f16s = false;   // packed for the split-f16 MFMA path of conv_mfma.hip (same bytes as the f32 packing)
+  // round 6: a second image of a small 1x1 convolution's weights, 16x16x32 A-fragment order (pack_g16_weights, K = 1), for
+  // the column-tile kernels of conv_cols.hip / attn_qkv_pack_f16s (has_wg == false: none planned)
+  size_t wg = 0;
+  bool has_wg = false;
 };
 
 // One channels-last split-f16 conv (gen16.hip); offsets in floats (2 halfs per float).
@@ -127,6 +131,10 @@ struct vsp_ctx {
   float act_scale = 16.f;
   unsigned* flags_host = nullptr;   // pinned + mapped status word the kernels raise VSP_FLAG_* in (vsp_status)
   unsigned* flags_dev = nullptr;    // its device address
+  long cols_min_blocks = 32;      // (VSP_COLS_MIN_BLOCKS)
+  long cols_blocks = 256;         // ... launch_conv routes a 1x1 convolution there up to this many 64-column tiles (VSP_COLS_BLOCKS)
+  bool cols = true;               // small-grid 1x1 convolutions, conv_o + LayerNorm and q | k | v + packing on the column-tile
+                                  // kernels (conv_cols.hip; VSP_COLS=0: the row-tiled kernels + separate LayerNorm / pack launches)
   bool trim_tails = true;         // ragged batches: the generator runs each utterance to length + 2 halo + 1 frames and fills the
                                   // padded tail from the steady state (VSP_TRIM_TAILS=0: to the padded length; bit-identical)
   // round 5, measured and NOT adopted (profiles/r05_resblock_chains_on_side_streams.txt): the ResBlocks of a generator stage

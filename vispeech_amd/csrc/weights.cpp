@@ -175,6 +175,11 @@ struct Planner {
     c.w = raw(packed_conv_floats(M, Cin, K));
     c.b = bias ? (long)raw((size_t)M) : -1;
     c.f16s = f16s;
+    // (conv_cols.hip: 1x1, whole 32-channel chunks up to 192 inputs, whole 16-row tiles up to the 576 rows of q | k | v)
+    if (f16s && K == 1 && Cin % 32 == 0 && Cin <= 192 && M % 16 == 0 && M >= 64 && M <= 576) {
+      c.wg = raw(packed_g16_halfs(M, Cin, 1) / 2);
+      c.has_wg = true;
+    }
     return c;
   }
   ClConv clconv(int Cout, int Cin, int K, int dil, int pad, int phases, int ups_p) {
@@ -401,6 +406,7 @@ struct Filler {
     if (c.f16s) check_f16_range(dense);
     if (c.f16s) pack_conv_weights_f16s(arena.data() + c.w, c.M, c.Cin, c.K, dense.data());
     else pack_conv_weights(arena.data() + c.w, c.M, c.Cin, c.K, dense.data());
+    if (c.has_wg) pack_g16_weights(reinterpret_cast<uint16_t*>(arena.data() + c.wg), c.M, c.Cin, 1, dense.data());
     if (c.b >= 0)
       for (int r = 0; r < c.M; ++r) arena[c.b + r] = b(r);
   }
