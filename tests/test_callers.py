@@ -443,3 +443,33 @@ def test_adopted_arena_needs_a_commit_and_carries_what_rank0_packed(dims, full_w
         o_arena.copy_(arena)
         with pytest.raises(VspError):
             other.commit_adopted()
+
+
+@gpu
+def test_first_streamed_chunk_leaves_long_before_the_whole_waveform(dims):
+    """on the 60 s utterance of BASELINE config 5 the service's first PCM16 chunk (64 frames) is on the
+    host well before the one-shot call -- what the reference's /tts does (inference_api.py:43-54) -- would return, and the
+    streamed bytes are the one-shot waveform."""
+    import time
+    from vispeech_amd.service import SynthesisService
+    from vispeech_amd.synth import synth_state_dict, workload
+    net = make_net()
+    net.load_state_dict(synth_state_dict(dims, seed=1234, infer_only=True))
+    svc = SynthesisService(net, chunk_frames=64)
+    batch = workload("C5")
+    noise = torch.from_numpy(batch["noise"]).to(net.device)
+    firsts, wholes = [], []
+    for _ in range(3):                                   # (the first pass allocates workspaces)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        it = svc.stream(batch, 0, noise=noise)
+        head = next(it)
+        firsts.append(time.perf_counter() - t0)
+        rest = b"".join(it)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        pcm = svc.synthesize(batch, 0, noise=noise)
+        wholes.append(time.perf_counter() - t1)
+    assert len(head) == 2 * 64 * 512
+    assert head + rest == pcm.tobytes()                  # byte-identical to the one-shot waveform
+    assert min(firsts[1:]) < 0.6 * min(wholes[1:]), (firsts, wholes)
