@@ -26,4 +26,21 @@ out = {"kernel": sub, "kernels": ktag, "lib_sha256": lib_sha, "generator": gen, 
        "hbm_bytes_per_launch": (fetch_b + write_b) / nf,
        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), KiB units, FETCH_SIZE x2 (gfx950 "
                  "wide-read correction, MI355X_MICROARCH.md section HBM)"}
+# per kernel FAMILY (bench.py's dominant_kernel reads the entry of its family): the fused-pair / chain kernels have names of
+# their own; the per-convolution kernel serves several families and stays one entry
+fams = {}
+for key, pat in (("pair64", "g16_pair<"), ("pair32", "g16_rw<"), ("chain32", "g16_rc<"), ("pair128", "g16_pp<"),
+                 ("conv_all_widths", "g16_conv"), ("ups_k4", "g16_ups<")):
+    def tot(path, counter):
+        s2 = 0.0; n2 = 0
+        for r in csv.DictReader(open(path)):
+            if pat in r['Kernel_Name'] and r['Counter_Name'] == counter:
+                s2 += float(r['Counter_Value']); n2 += 1
+        return s2, n2
+    ff, n1 = tot(fcsv, 'FETCH_SIZE')
+    ww, n2 = tot(wcsv, 'WRITE_SIZE')
+    if n1 and n1 == n2:
+        fams[key] = {"kernel": pat, "launches_per_step": n1 / steps, "fetch_bytes_per_launch": 2.0 * ff * 1024.0 / n1,
+                     "write_bytes_per_launch": ww * 1024.0 / n1, "hbm_bytes_per_launch": (2.0 * ff + ww) * 1024.0 / n1}
+out["families"] = fams
 print(json.dumps(out, indent=1))
