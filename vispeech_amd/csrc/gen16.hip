@@ -56,7 +56,14 @@ void pack_g16_weights(uint16_t* dst, int rows, int Cin, int K, const float* dens
       for (int tap = 0; tap < K; ++tap) {
         const float w = dense[((size_t)r * Cin + ci) * K + tap] * G16_WSCALE;   // (g16_common.h: exact, keeps lo normal)
         const _Float16 h = (_Float16)w;
-        const _Float16 l = (_Float16)(w - (float)h);
+        _Float16 l = (_Float16)(w - (float)h);
+#ifdef VSP_EXPERIMENTS
+        {   // power experiment: keep only the top VSP_WLO_BITS mantissa bits of the weights' lo parts (profiles/r06_power_and_clock.txt)
+          static int keep = -1;
+          if (keep < 0) { const char* e = getenv("VSP_WLO_BITS"); keep = e ? atoi(e) : 10; }
+          if (keep < 10) { uint16_t u; std::memcpy(&u, &l, 2); u &= (uint16_t)~((1u << (10 - keep)) - 1u); std::memcpy(&l, &u, 2); }
+        }
+#endif
         const int chunk = ci / 32, kk = ci % 32, mt = r / 16, lane = (r % 16) + 16 * (kk / 8), j = kk % 8;
         const size_t blk = (((size_t)chunk * K + tap) * nmt + mt) * 2;
         std::memcpy(dst + (blk * 64 + lane) * 8 + j, &h, 2);
