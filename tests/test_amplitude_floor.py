@@ -190,3 +190,11 @@ def test_activations_beyond_the_split_range_are_loud(weights, dims, latent):
     assert eng.status() & _lib.FLAG_NONFINITE_LATENT
     with pytest.raises(_lib.VspError):
         eng.check_numerics()
+    # ... and a duration that is not a number (or beyond any utterance) is counted as zero frames and reported -- by the
+    # time the frame counts are read back -- instead of overflowing the prefix sum into a garbage frame count
+    dur = batch["duration"].copy()
+    dur[1, 2] = np.inf
+    with pytest.raises(_lib.VspError, match="non-finite"):
+        net.infer(t(batch["phonemes"]), t(batch["lengths"]), sid=t(batch["sid"]), noise_scale=0.667, duration_control=t(dur),
+                  pitch_control=t(batch["f0"]), energy_control=t(batch["energy"]))
+    assert eng.status() == 0

@@ -33,5 +33,13 @@ for N in 1 2 4 8; do
 done
 VSP_TRIM_TAILS=0 python3 "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline > "$O/bench_untrimmed.json" 2>> "$O/bench.err" || true
 python3 "$R/bench.py" --workload C4 --steps 5 --warmup 2 --cpu-sample 2 --cpu-runs 1 > "$O/bench_c4.json" 2>> "$O/bench.err" || true
+# round 6: launch-by-launch timelines at the small operating points, time to first audio, power / clock under load,
+# per-family HBM bytes (profiles/traffic.json "families"), the two-rank loop with per-run verdicts
+rocprofv3 --kernel-trace --output-format csv -d "$O/trace_n8" -o t -- python3 "$R/bench.py" --shard-of 8 --shard-rank 0 --steps 4 --warmup 2 --profile-steps 0 --no-cpu-baseline > /dev/null 2>> "$O/bench.err" || true
+python3 "$R/tools/trace_timeline.py" "$O/trace_n8/t_kernel_trace.csv" > "$O/operating_point_n8_timeline.txt" || true
+python3 "$R/tools/trace_fused.py" "$O/trace_n8/t_kernel_trace.csv" 8 489 > "$O/operating_point_n8_generator.txt" 2>&1 || true
+(cd "$R" && python3 tools/ttfa.py 64 > "$O/ttfa.json" 2>> "$O/bench.err") || true
+(cd "$R" && tools/power_clock_sample.sh final/power_c3 "--steps 200 --warmup 5" > "$O/power.txt" 2>&1; tools/power_clock_sample.sh final/power_one "--workload C2 --batch 1 --steps 3000 --warmup 5" >> "$O/power.txt" 2>&1) || true
+(cd "$R" && tools/loop_two_rank.sh 10 final/two_rank_loop > /dev/null 2>&1) || true
 rm -f "$O"/trace*/t_kernel_trace.csv "$O"/pmc_*/p_agent_info.csv
 cat "$O/pytest_gpu.txt"; cut -c1-300 "$O/bench.json"; tail -3 "$O/generator_per_launch.txt"; cat "$O/traffic.json"

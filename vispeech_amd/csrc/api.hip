@@ -1129,7 +1129,7 @@ static int encode_impl(vsp_ctx* ctx, hipStream_t s, Ws& ws, int B, int Tp, const
   if (live) { ctx->fl_src = nullptr; ctx->fl_known_src = nullptr; }
   if (dctl && live) {
     r.chk(hipMemcpyAsync(duration, dctl, (size_t)B * Tp * sizeof(float), hipMemcpyDeviceToDevice, s), "dur copy");
-    r.chk(launch_duration_cumsum(duration, cum_dur, frame_lengths, B, Tp, s), "duration cumsum");
+    r.chk(launch_duration_cumsum(duration, cum_dur, frame_lengths, B, Tp, s, ctx->flags_dev), "duration cumsum");
     // (early_copy == false: the one-call form vsp_infer never reads the counts back -- nothing would consume the copy)
     if (r.ok() && early_copy && ctx->early_fl && early_frame_lengths_ready(ctx, B)) {
       hipError_t e = hipMemcpyAsync(ctx->fl_pinned, frame_lengths, (size_t)B * sizeof(int64_t), hipMemcpyDeviceToHost, s);
@@ -1190,7 +1190,7 @@ static int encode_impl(vsp_ctx* ctx, hipStream_t s, Ws& ws, int B, int Tp, const
   if (live) {
     r.chk(launch_energy(ectl, pred, escale, norm_e, energy, B * Tp, s), "energy");
     r.chk(launch_prenet_add(XV.p, XV.bs, XV.cs, r.A(m.epre_w), r.A(m.epre_b), norm_e, B, h, Tp, s), "energy_prenet");
-    if (!dctl) r.chk(launch_duration_cumsum(duration, cum_dur, frame_lengths, B, Tp, s), "duration cumsum");
+    if (!dctl) r.chk(launch_duration_cumsum(duration, cum_dur, frame_lengths, B, Tp, s, ctx->flags_dev), "duration cumsum");
   }
   if (ws.overflow) return ctx->fail(VSP_ERR_WORKSPACE, "encode workspace too small (need %zu bytes)", ws.cur);
   return r.rc;

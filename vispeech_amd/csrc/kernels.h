@@ -288,7 +288,7 @@ hipError_t launch_energy(const float* energy_ctl, const float* e_pred, float sca
                          float* energy, int n, hipStream_t s);
 // cum[b][i] = sum_{k<=i} max(int(d[b][k]),0); frame_lengths[b] = cum[b][Tp-1]
 hipError_t launch_duration_cumsum(const float* dur, int32_t* cum, int64_t* frame_lengths, int B, int Tp,
-                                  hipStream_t s);
+                                  hipStream_t s, unsigned* flags = nullptr);
 // out[b][c][f] = f < cum[b][Tp-1] ? x[b][c][upper_bound(cum[b], f)] : 0
 hipError_t launch_length_regulate(const float* x, long x_bs, long x_cs, const int32_t* cum, float* out,
                                   long o_bs, long o_cs, int B, int C, int Tp, int Tf, hipStream_t s);

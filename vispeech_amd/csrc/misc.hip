@@ -304,7 +304,8 @@ hipError_t launch_energy(const float* energy_ctl, const float* e_pred, float sca
 // reps_i = max(int(d_i), 0) (DPP shuffles, carry across 64-wide chunks), and the expand is a
 // per-frame upper_bound into that prefix sum.
 __global__ void __launch_bounds__(64) duration_cumsum_kernel(const float* __restrict__ dur, int32_t* __restrict__ cum,
-                                                             int64_t* __restrict__ frame_lengths, int Tp) {
+                                                             int64_t* __restrict__ frame_lengths, int Tp,
+                                                             unsigned* __restrict__ flags) {
   const int b = blockIdx.x, lane = threadIdx.x;
   int carry = 0;
   for (int base = 0; base < Tp; base += 64) {
@@ -313,6 +314,10 @@ __global__ void __launch_bounds__(64) duration_cumsum_kernel(const float* __rest
     if (i < Tp) {
       const float d = dur[(size_t)b * Tp + i];
       v = d > 0.f ? (int)d : 0;  // int() truncation, negatives -> 0 (models.py:424)
+      // a duration that is not a number, or beyond anything an utterance holds (2^20 frames = 3.4 hours): the predictor's
+      // activations left the split-f16 range, or the caller's tensor is broken -- counted as 0 frames and flagged
+      // (vsp_status) instead of overflowing the prefix sum into a garbage frame count
+      if (!(d <= 1048576.f)) { v = 0; if (flags) atomicOr(flags, VSP_FLAG_NONFINITE_LATENT); }
     }
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -326,8 +331,8 @@ __global__ void __launch_bounds__(64) duration_cumsum_kernel(const float* __rest
   if (lane == 0) frame_lengths[b] = carry;
 }
 hipError_t launch_duration_cumsum(const float* dur, int32_t* cum, int64_t* frame_lengths, int B, int Tp,
-                                  hipStream_t s) {
-  hipLaunchKernelGGL(duration_cumsum_kernel, dim3(B), dim3(64), 0, s, dur, cum, frame_lengths, Tp);
+                                  hipStream_t s, unsigned* flags) {
+  hipLaunchKernelGGL(duration_cumsum_kernel, dim3(B), dim3(64), 0, s, dur, cum, frame_lengths, Tp, flags);
   return hipGetLastError();
 }
 
