@@ -12,11 +12,11 @@ export VSP_BENCH_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0 VSP_BENCH_PG_TIMEOUT=
 cd "$R"
 : > "$O/summary.txt"
 for i in $(seq 1 "$N"); do
-  t0=$(date +%s.%N)
+  t0=$(date +%s%N)
   timeout 120 python3 bench.py --gpus 2 --batch 6 --steps 2 --warmup 1 "$@" > "$O/run_$i.out" 2> "$O/run_$i.err"
   rc=$?
-  t1=$(date +%s.%N)
+  t1=$(date +%s%N)
   if [ $rc -eq 0 ] && grep -q '^{' "$O/run_$i.out"; then v=ok; rm -f "$O/run_$i.err" "$O/run_$i.out"; else v=BAD; fi
-  printf "run %2d %s rc=%d %.1fs\n" "$i" "$v" "$rc" "$(echo "$t1 - $t0" | bc)" | tee -a "$O/summary.txt"
+  printf "run %2d %s rc=%d %d.%ds\n" "$i" "$v" "$rc" "$(( (t1 - t0) / 1000000000 ))" "$(( (t1 - t0) / 100000000 % 10 ))" | tee -a "$O/summary.txt"
 done
 echo "ok=$(grep -c ' ok rc=0' "$O/summary.txt") bad=$(grep -c ' BAD ' "$O/summary.txt") of $N" | tee -a "$O/summary.txt"
