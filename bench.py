@@ -19,7 +19,10 @@ rank 0 over RCCL once before timing, and end every step with the gather of the w
 exchange the north star names.  value = valid samples of all ranks / max-over-ranks time; the line also carries the
 per-rank step times (min / max) and the gather's share of a step (a second timed pass without the gather).
 
-A step = one full infer() with all inputs resident in HBM.  The headline is timed with profiling OFF; the
+A step = one full infer() of one batch with all inputs resident in HBM.  By default TWO batches are in flight per GPU
+(--in-flight 2: two contexts on two HIP streams, step k on context k % 2 -- the frame-rate half of batch k + 1, ~120 short
+launches that leave most of the chip idle, overlaps the generator of batch k); `value` is the throughput of the K timed
+steps, `single_batch` the same K steps with one batch in flight (a step = one batch start to end: the latency figure).  The headline is timed with profiling OFF; the
 per-kernel-class event timing behind `roofline` comes from a second, untimed pass of `--profile-steps` steps.
 At N = 1 rank 0 then times the parity-pinned CPU oracle on a bounded sample of the same batch (`cpu_baseline`)
 and checks the GPU waveform of those utterances against it (`parity`).
@@ -73,6 +76,12 @@ def parse(argv=None):
                    help="one GPU, no process group: synthesise ONLY rank --shard-rank's shard_range slice of the batch under the "
                         "GLOBAL frame padding -- the per-GPU operating point a --gpus N run lands on (profiles/r05_per_rank_*)")
     p.add_argument("--shard-rank", type=int, default=0)
+    p.add_argument("--in-flight", type=int, default=2,
+                   help="batches in flight per GPU: N contexts on N HIP streams, step k on context k %% N, so that the frame-rate "
+                        "half of batch k + 1 (~120 short launches that leave most of the chip idle) overlaps the generator of "
+                        "batch k.  Every step is still one full infer() of one batch; `value` is the throughput of the K timed "
+                        "steps.  The line also carries `single_batch`: the same K steps with ONE batch in flight (--in-flight 1: "
+                        "a step = one batch start to end, the latency figure and rounds 1-5's headline)")
     p.add_argument("--dump-wave", default=None,
                    help="test hook: rank 0 writes the waveform batch of one more (untimed) step -- gathered over the ranks when "
                         "there is a process group -- to this .npy file")
@@ -273,6 +282,22 @@ def main():
         broadcast_weights(net._engine, sd, src=0)
         torch.cuda.synchronize()
     eng = net._engine
+    # --in-flight N: N - 1 more contexts (their own packed weights and workspaces), each on its own stream
+    if args.in_flight < 1:
+        raise SystemExit("--in-flight N >= 1")
+    import contextlib
+    nets, streams = [net], [None]
+    for _ in range(args.in_flight - 1):
+        m = SynthesizerTrn(*a, device=dev, **kw).eval()
+        if not use_dist:
+            m.load_state_dict(sd)
+        else:
+            broadcast_weights(m._engine, sd, src=0)      # (every rank takes part: same number of contexts everywhere)
+            torch.cuda.synchronize()
+        nets.append(m)
+    if args.in_flight > 1:
+        streams = [torch.cuda.Stream(dev) for _ in nets]
+    step_no = [0]
 
     # ---- the batch.  C4: one global batch, this rank's slice; otherwise one batch per rank
     wl = dict(WORKLOADS[args.workload])
@@ -332,10 +357,14 @@ def main():
         gatherer = BatchGatherer(counts, (1, 512 * tf_global), torch.float32, dev, dst=0)
 
     def step():
-        o, x_mask, (z, z_p, m_p, logs_p), duration, f0, energy = net.infer(
-            ph, ln, sid=sid, noise_scale=0.667, noise=noise, t_f=tf_global, **ctl)
-        if gatherer is not None:
-            gatherer.start(o)
+        i = step_no[0] % len(nets)
+        step_no[0] += 1
+        # (the gather is started INSIDE the step's stream: it orders itself behind that stream's work by an event)
+        with (torch.cuda.stream(streams[i]) if streams[i] is not None else contextlib.nullcontext()):
+            o, x_mask, (z, z_p, m_p, logs_p), duration, f0, energy = nets[i].infer(
+                ph, ln, sid=sid, noise_scale=0.667, noise=noise, t_f=tf_global, **ctl)
+            if gatherer is not None:
+                gatherer.start(o)
         last.update(o=o, z=z, duration=duration)
         return o
 
@@ -362,6 +391,23 @@ def main():
     dt = time.perf_counter() - t0
     arm(extra=4.0 * per_step_guess * args.steps)
     dt_rank = dt
+    # ONE batch in flight (a step = one batch start to end: the latency figure, and the headline of rounds 1-5): the same K
+    # steps once more on context 0 alone (untimed for `value`)
+    dt_single = None
+    if len(nets) > 1:
+        keep_n, keep_s = nets, streams
+        nets, streams = nets[:1], streams[:1]
+        for _ in range(2):
+            step()
+        drain()
+        arm(extra=4.0 * per_step_guess * args.steps)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        drain()
+        dt_single = time.perf_counter() - t1
+        nets, streams = keep_n, keep_s
+        arm(extra=4.0 * per_step_guess * args.steps)
     # the gather's share of a step: the same K steps once more WITHOUT the exchange (untimed for `value`)
     dt_nogather = None
     if gatherer is not None:
@@ -377,6 +423,8 @@ def main():
     prof = {}
     if args.profile_steps > 0:
         arm()
+        nets, streams = nets[:1], streams[:1]          # (the per-launch event pass runs one batch at a time on context 0)
+        torch.cuda.synchronize()
         eng.profile(True)
         for _ in range(args.profile_steps):
             step()
@@ -432,7 +480,7 @@ def main():
         if rank == 0:
             np.save(args.dump_wave, torch.cat([x.reshape(x.shape[0], -1) for x in shards], dim=0).cpu().numpy())
 
-    tt = torch.tensor([dt, float(valid_samples), dt_nogather or dt], dtype=torch.float64, device=dev)
+    tt = torch.tensor([dt, float(valid_samples), dt_nogather or dt, dt_single or dt], dtype=torch.float64, device=dev)
     rank_ms = [dt_rank / args.steps * 1e3]
     if use_dist:
         mx = tt.clone()
@@ -444,6 +492,8 @@ def main():
         dt, total_valid = float(mx[0].item()), float(sm[1].item())
         rank_ms = [float(mn[0].item()) / args.steps * 1e3, float(mx[0].item()) / args.steps * 1e3]
         dt_nogather = float(mx[2].item())
+        if dt_single is not None:
+            dt_single = float(mx[3].item())
     else:
         total_valid = float(valid_samples)
 
@@ -468,7 +518,11 @@ def main():
                        "utterances_per_gpu": B, "global_batch": B_all * (1 if sharded_global else world),
                        "padded_frames": tf_global, "valid_samples_per_step": int(total_valid),
                        "frames_padded": int(B * tf_global), "frames_computed": frames_computed,
-                       "parallelism": f"shard{world}", "generator": gen_mode, "controls": args.controls},
+                       "parallelism": f"shard{world}", "generator": gen_mode, "controls": args.controls,
+                       "batches_in_flight": args.in_flight},
+            "single_batch": ({"what": "the same K steps with ONE batch in flight (context 0 alone): a step = one batch start to end",
+                              "ms_per_step": dt_single / args.steps * 1e3, "value": total_valid * args.steps / dt_single,
+                              "rtf": (dt_single / args.steps) / audio_s} if dt_single is not None else None),
             "emulated_rank": ({"rank": args.shard_rank, "of": args.shard_of, "utterances": [lo, hi]} if args.shard_of else None),
             "n_ranks_seen": n_ranks_seen,
             "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},

@@ -139,3 +139,17 @@ def test_dump_wave_hook_on_one_gpu_over_gloo(tmp_path):
     assert d["n_ranks_seen"] == 2
     a, b = np.load(got), _one_gpu_wave(tmp_path, "--batch", "6")
     assert a.shape == b.shape and np.abs(a - b).max() <= 1e-5 * np.abs(b).max()
+
+
+def test_batches_in_flight_are_disclosed_and_the_single_batch_figure_rides_along(tmp_path):
+    """Round 6: by default two batches are in flight per GPU (two contexts on two streams: the frame-rate half of batch
+    k + 1 overlaps the generator of batch k).  The line says so, carries the one-batch-in-flight figure of the same K
+    steps beside it, and --in-flight 1 is rounds 1-5's headline form; both deliver the same waveforms."""
+    a, b = tmp_path / "two.npy", tmp_path / "one.npy"
+    d2 = run_bench("--batch", "4", "--no-cpu-baseline", "--dump-wave", str(a), gpus=1, backend="nccl")
+    d1 = run_bench("--batch", "4", "--no-cpu-baseline", "--in-flight", "1", "--dump-wave", str(b), gpus=1, backend="nccl")
+    assert d2["config"]["batches_in_flight"] == 2 and d1["config"]["batches_in_flight"] == 1
+    sb = d2["single_batch"]
+    assert sb and sb["ms_per_step"] > 0 and sb["value"] > 0 and d1["single_batch"] is None
+    assert d2["roofline"]["launches"] == 51 == d1["roofline"]["launches"]          # the profiled pass runs one batch at a time
+    assert np.array_equal(np.load(a), np.load(b))                                  # same kernels on the same inputs: same bits

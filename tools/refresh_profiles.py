@@ -47,6 +47,9 @@ for f, k in (("bench_c2", "C2"), ("bench_c5", "C5"), ("bench_controls_duration",
         continue
     x = json.loads(open(path).read().strip().splitlines()[-1])
     out[k] = {kk: x[kk] for kk in ("value", "unit", "ms_per_step", "rtf", "dtype")}
+    out[k]["batches_in_flight"] = x["config"].get("batches_in_flight", 1)
+    if x.get("single_batch"):
+        out[k]["single_batch"] = {kk: x["single_batch"][kk] for kk in ("ms_per_step", "value", "rtf")}
     out[k]["workload"] = x["config"]["workload"]
     out[k]["padded_frames"] = x["config"]["padded_frames"]
     out[k]["valid_samples_per_step"] = x["config"]["valid_samples_per_step"]
@@ -66,14 +69,19 @@ for N in (1, 2, 4, 8):
         x = json.loads(open(path).read().strip().splitlines()[-1]); r = x["roofline"]
         ops[f"N={N}"] = {"utterances_per_gpu": x["config"]["utterances_per_gpu"], "padded_frames": x["config"]["padded_frames"],
                          "ms_per_step": x["ms_per_step"], "samples_per_s_per_gpu": x["value"],
+                         "batches_in_flight": x["config"].get("batches_in_flight", 1),
+                         "single_batch_ms_per_step": (x.get("single_batch") or {}).get("ms_per_step"),
+                         "single_batch_samples_per_s_per_gpu": (x.get("single_batch") or {}).get("value"),
                          "generator_ms": r["kernel_ms_per_step"], "generator_launches": r["launches"],
                          "attention_ms": r["attention"]["ms_per_step"], "frame_rate_convs_ms": r["frame_rate_convs"]["ms_per_step"],
                          "frame_rate_launches": r["frame_rate_convs"]["launches"],
                          "families_ms": (r.get("dominant_kernel") or {}).get("families_ms_per_step")}
 if ops:
     base = ops.get("N=1", {}).get("samples_per_s_per_gpu")
+    base1 = ops.get("N=1", {}).get("single_batch_samples_per_s_per_gpu")
     for k, v in ops.items():
         v["per_gpu_rate_vs_N1"] = v["samples_per_s_per_gpu"] / base if base else None
+        v["single_batch_per_gpu_rate_vs_N1"] = (v["single_batch_samples_per_s_per_gpu"] / base1) if base1 and v.get("single_batch_samples_per_s_per_gpu") else None
         v["predicted_whole_job_samples_per_s"] = v["samples_per_s_per_gpu"] * int(k[2:])   # (before the gather: an upper bound)
     path = os.path.join(F, "bench_untrimmed.json")
     if os.path.exists(path):
