@@ -18,7 +18,7 @@ print('N=$N B=%d  %.2f ms/step  %.1f M samples/s | generator %.2f ms (%d launche
 done 2>&1 | tee "$O/summary.txt"
 for N in 4 8; do
   B=$((64 / N))
-  rocprofv3 --kernel-trace --output-format csv -d "$O/trace_n$N" -o t -- python3 "$R/bench.py" --shard-of $N --shard-rank 0 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> "$O/trace_n$N.err" || true
+  rocprofv3 --kernel-trace --output-format csv -d "$O/trace_n$N" -o t -- python3 "$R/bench.py" --in-flight 1 --shard-of $N --shard-rank 0 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> "$O/trace_n$N.err" || true
   python3 "$R/tools/trace_fused.py" "$(find "$O/trace_n$N" -name '*kernel_trace.csv' | head -1)" $B 489 > "$O/per_launch_n$N.txt" 2>&1 || true
   python3 "$R/tools/trace_timeline.py" "$(find "$O/trace_n$N" -name '*kernel_trace.csv' | head -1)" > "$O/timeline_n$N.txt" 2>&1 || true
   rm -rf "$O/trace_n$N"

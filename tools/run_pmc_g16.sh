@@ -15,7 +15,7 @@ GROUPS_=(
 i=0
 for G in "${GROUPS_[@]}"; do
   O="$R/gpurun_out/$TAG/g$i"; rm -rf "$O"; mkdir -p "$O"
-  rocprofv3 --pmc $G --output-format csv -d "$O" -o p -- python3 "$R/bench.py" "$@" --steps 1 --warmup 1 --profile-steps 0 --no-cpu-baseline > /dev/null 2> "$O/err.txt" || echo "pass $i failed: $(tail -2 $O/err.txt)"
+  rocprofv3 --pmc $G --output-format csv -d "$O" -o p -- python3 "$R/bench.py" --in-flight 1 "$@" --steps 1 --warmup 1 --profile-steps 0 --no-cpu-baseline > /dev/null 2> "$O/err.txt" || echo "pass $i failed: $(tail -2 $O/err.txt)"
   i=$((i+1))
 done
 python3 "$R/tools/pmc_g16_table.py" $(ls "$R"/gpurun_out/$TAG/g*/p_counter_collection.csv) > "$R/gpurun_out/$TAG/table.txt" || true

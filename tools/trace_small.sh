@@ -9,7 +9,7 @@ for kv in "$@"; do export "$kv"; done
 O="$R/gpurun_out/$TAG"; rm -rf "$O"; mkdir -p "$O"
 if [ "$S" = "one" ]; then W="--workload C2 --batch 1"; else W="--shard-of $S --shard-rank 0"; fi
 # shellcheck disable=SC2086
-rocprofv3 --kernel-trace --output-format csv -d "$O/tr" -o t -- python3 "$R/bench.py" $W --steps 3 --warmup 2 --no-cpu-baseline --profile-steps 0 > "$O/bench.json" 2> "$O/bench.err" || true
+rocprofv3 --kernel-trace --output-format csv -d "$O/tr" -o t -- python3 "$R/bench.py" --in-flight 1 $W --steps 3 --warmup 2 --no-cpu-baseline --profile-steps 0 > "$O/bench.json" 2> "$O/bench.err" || true
 python3 "$R/tools/trace_timeline.py" "$(find "$O/tr" -name '*kernel_trace.csv' | head -1)" > "$O/timeline.txt" 2>&1 || true
 rm -rf "$O/tr"
 tail -25 "$O/timeline.txt"
