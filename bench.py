@@ -285,19 +285,17 @@ def main():
     # --in-flight N: N - 1 more contexts (their own packed weights and workspaces), each on its own stream
     if args.in_flight < 1:
         raise SystemExit("--in-flight N >= 1")
-    import contextlib
-    nets, streams = [net], [None]
-    for _ in range(args.in_flight - 1):
-        m = SynthesizerTrn(*a, device=dev, **kw).eval()
+    from vispeech_amd.pipeline import InFlightPool
+
+    def load_more(m):
         if not use_dist:
             m.load_state_dict(sd)
         else:
             broadcast_weights(m._engine, sd, src=0)      # (every rank takes part: same number of contexts everywhere)
             torch.cuda.synchronize()
-        nets.append(m)
-    if args.in_flight > 1:
-        streams = [torch.cuda.Stream(dev) for _ in nets]
-    step_no = [0]
+
+    pool_all = InFlightPool(lambda: SynthesizerTrn(*a, device=dev, **kw).eval(), load_more, n=args.in_flight, first=net)
+    pool = [pool_all]                                    # (the pool the steps run on: all contexts, or context 0 alone)
 
     # ---- the batch.  C4: one global batch, this rank's slice; otherwise one batch per rank
     wl = dict(WORKLOADS[args.workload])
@@ -357,14 +355,11 @@ def main():
         gatherer = BatchGatherer(counts, (1, 512 * tf_global), torch.float32, dev, dst=0)
 
     def step():
-        i = step_no[0] % len(nets)
-        step_no[0] += 1
         # (the gather is started INSIDE the step's stream: it orders itself behind that stream's work by an event)
-        with (torch.cuda.stream(streams[i]) if streams[i] is not None else contextlib.nullcontext()):
-            o, x_mask, (z, z_p, m_p, logs_p), duration, f0, energy = nets[i].infer(
-                ph, ln, sid=sid, noise_scale=0.667, noise=noise, t_f=tf_global, **ctl)
-            if gatherer is not None:
-                gatherer.start(o)
+        g = gatherer
+        (o, x_mask, (z, z_p, m_p, logs_p), duration, f0, energy), _ = pool[0].infer(
+            ph, ln, sid=sid, noise_scale=0.667, noise=noise, t_f=tf_global,
+            after=(lambda res: g.start(res[0])) if g is not None else None, **ctl)
         last.update(o=o, z=z, duration=duration)
         return o
 
@@ -394,9 +389,8 @@ def main():
     # ONE batch in flight (a step = one batch start to end: the latency figure, and the headline of rounds 1-5): the same K
     # steps once more on context 0 alone (untimed for `value`)
     dt_single = None
-    if len(nets) > 1:
-        keep_n, keep_s = nets, streams
-        nets, streams = nets[:1], streams[:1]
+    if len(pool_all) > 1:
+        pool[0] = pool_all.restrict(1)
         for _ in range(2):
             step()
         drain()
@@ -406,7 +400,7 @@ def main():
             step()
         drain()
         dt_single = time.perf_counter() - t1
-        nets, streams = keep_n, keep_s
+        pool[0] = pool_all
         arm(extra=4.0 * per_step_guess * args.steps)
     # the gather's share of a step: the same K steps once more WITHOUT the exchange (untimed for `value`)
     dt_nogather = None
@@ -423,7 +417,7 @@ def main():
     prof = {}
     if args.profile_steps > 0:
         arm()
-        nets, streams = nets[:1], streams[:1]          # (the per-launch event pass runs one batch at a time on context 0)
+        pool[0] = pool_all.restrict(1)                 # (the per-launch event pass runs one batch at a time on context 0)
         torch.cuda.synchronize()
         eng.profile(True)
         for _ in range(args.profile_steps):
