@@ -365,7 +365,10 @@ int vsp_cl_conv1d(void* stream, int B, int T, int Cin, int Cout, int K, int dila
  * 1 relu, 2 WN gate tanh(rows [0, Cout/2)) * sigmoid(rows [Cout/2, Cout)) of interleaved 32-row tiles (then the output
  * has Cout / 2 rows; commons.py:100-107; no residual with the gate); then + res [B][rows][T], then * mask when mask_out.  K odd,
  * (K - 1) * dilation + 3 <= 64, T % 4 == 0 or T == 1 (the cond(g) projections of one time step).  split_f16 = 1: fp32-accurate split-f16 MFMA (the default path of the library),
- * 0: f32 MFMA.  Reference: torch.nn.Conv1d as used in attentions.py:138-145, 277-285, modules.py:148-176. */
+ * 0: f32 MFMA, 2 (round 6): the split-f16 COLUMN-TILE kernel -- every output row of a 64-column tile in one block, what the
+ * path uses for the 1x1 convolutions of mid-size grids -- K = 1, Cin 96 or 192, Cout a multiple of 16 in [64, 576], act 0,
+ * no in_act (VSP_ERR_UNSUPPORTED otherwise).  Reference: torch.nn.Conv1d as used in attentions.py:138-145, 277-285,
+ * modules.py:148-176. */
 int vsp_conv1d(void* stream, int B, int T, int Cin, int Cout, int K, int dilation, const float* x, const float* w_host,
                const float* bias_host, const int64_t* lengths, int mask_in, int in_act, float in_slope, int act,
                const float* res, int mask_out, int split_f16, float* out);

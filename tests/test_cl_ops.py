@@ -410,6 +410,50 @@ def test_conv1d_matches_torch(lib, cin, cout, k, dil, act, b, t):
         assert rel_err(out.cpu().numpy(), y.numpy()) <= TOL, (split, mask_in, in_act, use_res, mask_out)
 
 
+@pytest.mark.parametrize("cin,cout", [(192, 192), (192, 384), (96, 192), (192, 96), (192, 576), (192, 64), (96, 384), (192, 208)])
+@pytest.mark.parametrize("b,t", [(1, 4), (3, 60), (2, 64), (2, 68), (1, 488), (5, 132)])
+def test_column_tile_conv1x1_matches_torch(lib, cin, cout, b, t):
+    """The column-tile kernel (conv_cols.hip, round 6; vsp_conv1d split_f16 = 2) as a stand-alone operator: every row
+    count it serves in the path (q | k | v 576, res_skip / projection 384, conv_o / pre / skip 192, post 96) and ragged
+    ones, 96 and 192 input channels, column counts on and off the 64-column tile, input and output masks, residual --
+    against torch in fp64.  Shapes outside its range are refused, not mis-computed."""
+    r = np.random.Generator(np.random.PCG64(cin * 11 + cout * 5 + t + b))
+    x = r.standard_normal((b, cin, t)).astype(np.float32)
+    w = (r.standard_normal((cout, cin, 1)) / np.sqrt(cin)).astype(np.float32)
+    bias = r.standard_normal(cout).astype(np.float32)
+    res = r.standard_normal((b, cout, t)).astype(np.float32)
+    lens = np.asarray([max(1, t - 3 * i - (i % 2)) for i in range(b)], dtype=np.int64)
+    xd, rd, ld = torch.from_numpy(x).cuda(), torch.from_numpy(res).cuda(), torch.from_numpy(lens).cuda()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    mask = (np.arange(t)[None, :] < lens[:, None]).astype(np.float64)[:, None, :]
+    for mask_in, use_res, mask_out in ((1, 1, 1), (0, 0, 0), (0, 1, 0)):
+        out = torch.full((b, cout, t), float("nan"), device="cuda")
+        rc = lib.vsp_conv1d(stream, b, t, cin, cout, 1, 1, P(xd), w.ctypes.data_as(C.c_void_p), bias.ctypes.data_as(C.c_void_p),
+                            P(ld), mask_in, 0, 0.0, 0, P(rd) if use_res else None, mask_out, 2, P(out))
+        assert rc == 0, rc
+        xt = torch.from_numpy(x).double()
+        if mask_in:
+            xt = xt * torch.from_numpy(mask)
+        y = F.conv1d(xt, torch.from_numpy(w).double(), torch.from_numpy(bias).double())
+        if use_res:
+            y = y + torch.from_numpy(res).double()
+        if mask_out:
+            y = y * torch.from_numpy(mask)
+        assert rel_err(out.cpu().numpy(), y.numpy()) <= TOL, (mask_in, use_res, mask_out)
+
+
+def test_column_tile_conv1x1_refuses_what_it_does_not_cover(lib):
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for cin, cout, k, act in ((192, 192, 3, 0), (128, 192, 1, 0), (192, 32, 1, 0), (192, 200, 1, 0), (192, 640, 1, 0), (192, 192, 1, 1)):
+        x = torch.zeros(1, cin, 64, device="cuda")
+        out = torch.zeros(1, cout, 64, device="cuda")
+        w = np.zeros((cout, cin, k), dtype=np.float32)
+        bias = np.zeros(cout, dtype=np.float32)
+        rc = lib.vsp_conv1d(stream, 1, 64, cin, cout, k, 1, P(x), w.ctypes.data_as(C.c_void_p), bias.ctypes.data_as(C.c_void_p),
+                            None, 0, 0, 0.0, act, None, 0, 2, P(out))
+        assert rc == -7, (cin, cout, k, act, rc)             # VSP_ERR_UNSUPPORTED
+
+
 def test_conv1d_same_utterance_agrees_across_batch_sizes(lib):
     """launch_conv picks the channel-split, the one-barrier-per-K-taps or the throughput kernel from the GRID
     size, and the channel-split kernel sums in a different order -- the same utterance alone and inside a batch of 16

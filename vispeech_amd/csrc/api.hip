@@ -1957,6 +1957,23 @@ int vsp_conv1d(void* stream, int B, int T, int Cin, int Cout, int K, int dilatio
   a.in_mask = mask_in ? 1 : 0; a.in_act = in_act ? 1 : 0; a.in_slope = in_slope;
   a.act = act; a.alpha = 1.f; a.div = 1.f; a.mask_post = mask_out ? 1 : 0;
   a.f16s = split_f16 ? 1 : 0;
+  if (split_f16 == 2) {
+    // the column-tile form (conv_cols.hip: every output row of a 64-column tile in one block) as a stand-alone operator:
+    // the same weights in 16x16x32 A-fragment order; refused where that kernel does not apply
+    std::vector<uint16_t> wgh(packed_g16_halfs(Cout, Cin, 1));
+    DevBuf wgd;
+    if (K != 1 || Cin % 32 || Cout % 16) return VSP_ERR_UNSUPPORTED;
+    pack_g16_weights(wgh.data(), Cout, Cin, 1, wd.data());
+    e = wgd.alloc(wgh.size() * 2);
+    if (e == hipSuccess) e = hipMemcpyAsync(wgd.p, wgh.data(), wgh.size() * 2, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return op_rc(e);
+    a.wg = static_cast<const uint16_t*>(wgd.p);
+    if (!conv_cols_supported(a)) return VSP_ERR_UNSUPPORTED;
+    e = launch_conv_cols(a, B, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    return op_rc(e);
+  }
   e = launch_conv(a, B, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   return op_rc(e);
