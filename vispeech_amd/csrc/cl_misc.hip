@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(256) conv_post_cl_kernel(const float* __restri
     o[(size_t)b * o_bs + t] = tanhf(acc);
     // an activation beyond the split-f16 range turns into inf / NaN inside the matrix kernels (g16_common.h) and arrives
     // here: raise the context's sticky flag (vsp_status) -- rare, so the atomic costs nothing
-    if (flags && !(fabsf(acc) <= 3.0e38f)) atomicOr(flags, VSP_FLAG_NONFINITE_WAVE);
+    if (flags && !(fabsf(acc) <= 3.0e38f)) vsp_raise_flag(flags, VSP_FLAG_NONFINITE_WAVE);
   }
 }
 hipError_t launch_conv_post_cl(const float* x, long x_bs, int x_ts, const float* w, int C, int K, float slope,

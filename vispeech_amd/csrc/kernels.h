@@ -101,6 +101,11 @@ constexpr float G16_WSCALE = G16_WSCALE_V, G16_UNSCALE = G16_UNSCALE_V;
 // |lo| <= 2^-10 |x|), two instructions more.  VSP_SPLIT_FORM=0 builds that form (timing A/B only; it saturates).
 // (The operands come from compiler-generated vector instructions, never straight from an MFMA result: see the hazard
 // note in g16_common.h.)
+// A kernel reports a numeric-range event in the context's status word (vsp_status): pinned host memory mapped into the
+// device's address space, so the OR is a SYSTEM-scope atomic (the host reads / clears the same word without synchronising)
+__device__ __forceinline__ void vsp_raise_flag(unsigned* flags, unsigned bit) {
+  __hip_atomic_fetch_or(flags, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 #ifndef VSP_SPLIT_FORM
 #define VSP_SPLIT_FORM 1
 #endif

@@ -317,7 +317,7 @@ __global__ void __launch_bounds__(64) duration_cumsum_kernel(const float* __rest
       // a duration that is not a number, or beyond anything an utterance holds (2^20 frames = 3.4 hours): the predictor's
       // activations left the split-f16 range, or the caller's tensor is broken -- counted as 0 frames and flagged
       // (vsp_status) instead of overflowing the prefix sum into a garbage frame count
-      if (!(d <= 1048576.f)) { v = 0; if (flags) atomicOr(flags, VSP_FLAG_NONFINITE_LATENT); }
+      if (!(d <= 1048576.f)) { v = 0; if (flags) vsp_raise_flag(flags, VSP_FLAG_NONFINITE_LATENT); }
     }
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -378,7 +378,7 @@ __global__ void reparam_kernel(const float* __restrict__ m_p, const float* __res
   if (copy) copy[i] = v;        // (the tensor the inverse flow then transforms in place: saves a copy launch)
   // the frame-rate stages behind m_p / logs_p (text encoder, frame prior network, projection) left the split-f16 range
   // (conv_mfma.hip: an operand beyond +-65504 becomes inf) or the caller's noise is not finite: sticky flag, vsp_status
-  if (flags && !(fabsf(v) <= 3.0e38f)) atomicOr(flags, VSP_FLAG_NONFINITE_LATENT);
+  if (flags && !(fabsf(v) <= 3.0e38f)) vsp_raise_flag(flags, VSP_FLAG_NONFINITE_LATENT);
 }
 hipError_t launch_reparam(const float* m_p, const float* logs_p, const float* noise, float noise_scale, float* z_p,
                           long n, hipStream_t s, float* copy, unsigned* flags) {
@@ -499,7 +499,7 @@ __global__ void __launch_bounds__(128) conv_post_kernel(const float* __restrict_
     const int t = t0 + tl + n;
     if (t < T) {
       ob[t] = tanhf(acc[n]);
-      if (flags && !(fabsf(acc[n]) <= 3.0e38f)) atomicOr(flags, VSP_FLAG_NONFINITE_WAVE);
+      if (flags && !(fabsf(acc[n]) <= 3.0e38f)) vsp_raise_flag(flags, VSP_FLAG_NONFINITE_WAVE);
     }
   }
 }
