@@ -508,7 +508,8 @@ def main():
             "config": {"workload": f"{args.workload}: {B_all} {WL_TEXT.get(args.workload, 'utterances')}"
                                    f"{split_text}, 44.1 kHz, hop 512, "
                                    f"{ {'all': 'phoneme/duration/F0/energy/noise supplied', 'duration': 'phoneme/duration/noise supplied, F0 and energy PREDICTED', 'none': 'phonemes + noise supplied, duration / F0 / energy PREDICTED'}[args.controls] }"
-                                   ", random-init (synthetic) weights of configs/config.json",
+                                   ", random-init (synthetic) weights of configs/config.json"
+                                   + (f"; {args.in_flight} batches in flight per GPU (single_batch = one)" if args.in_flight > 1 else ""),
                        "utterances_per_gpu": B, "global_batch": B_all * (1 if sharded_global else world),
                        "padded_frames": tf_global, "valid_samples_per_step": int(total_valid),
                        "frames_padded": int(B * tf_global), "frames_computed": frames_computed,
