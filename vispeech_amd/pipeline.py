@@ -4,8 +4,8 @@ One ``SynthesizerTrn.infer`` is two halves of very different shape: a phoneme- /
 that leave most of the chip idle (dependent chains of 5-20 us kernels) and a vocoder that fills it.  Consecutive
 requests are independent, so a server keeps N contexts of the same model -- each with its own packed weights and
 workspaces -- on N HIP streams and issues request k on context k % N: the frame-rate half of request k + 1 overlaps the
-vocoder of request k.  Measured on one MI355X (profiles/r06_final_*): the 64-utterance batch 69.1 -> 67.4 ms per batch,
-8 utterances 10.6 -> 9.3 ms, one utterance 3.15 -> 2.09 ms, the 60 s utterance 15.0 -> 13.15 ms (throughput; the latency of one
+vocoder of request k.  Measured on one MI355X (profiles/r06_final_*): the 64-utterance batch 71.6 -> 70.0 ms per batch,
+8 utterances 10.8 -> 9.5 ms, one utterance 3.11 -> 2.09 ms, the 60 s utterance 15.5 -> 13.6 ms (throughput; the latency of one
 request is unchanged).  The reference has no counterpart (its app serialises requests behind one lock,
 inference_api.py:13, 37); ``bench.py --in-flight N`` times exactly this object.
 """
