@@ -178,6 +178,34 @@ def test_service_is_single_flight_and_never_queues():
         assert (w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()) == (1, 2, 44100, 12)
 
 
+def test_pooled_service_serves_n_requests_and_refuses_the_next():
+    """Round 6: N single-flight slots (one per context of an InFlightPool) -- the reference's "refuse, never queue" with N
+    locks instead of one (inference_api.py:13, 37): two requests run side by side, the third is refused at once, a freed
+    slot serves again."""
+    from types import SimpleNamespace
+    from vispeech_amd.service import Busy, PooledSynthesisService, pcm16
+    nets = [_FakeNet(), _FakeNet()]
+    svc = PooledSynthesisService(SimpleNamespace(nets=nets, streams=[None]))
+    batch = dict(phonemes=np.zeros((2, 3), np.int64), lengths=np.array([3, 3]), sid=np.array([0, 1]))
+    res = {}
+    th = [threading.Thread(target=lambda k=k: res.update({k: svc.synthesize(batch)})) for k in range(2)]
+    th[0].start()
+    assert nets[0].started.wait(10) and not svc.busy          # slot 0 taken, slot 1 free
+    th[1].start()
+    assert nets[1].started.wait(10) and svc.busy              # both taken
+    assert svc.synthesize(batch) is None and svc.wav_bytes(batch) is None
+    with pytest.raises(Busy):
+        svc.stream(batch)
+    nets[1].go.set()
+    th[1].join(10)
+    assert not svc.busy                                        # slot 1 is free again while slot 0 still runs
+    assert svc.synthesize(batch) is not None                   # ... and serves (its net no longer blocks)
+    nets[0].go.set()
+    th[0].join(10)
+    for k in range(2):
+        np.testing.assert_array_equal(res[k], pcm16(torch.linspace(-1, 1, 24)[:8]))
+
+
 # ------------------------------------------------------------------------------------------ GPU
 gpu = pytest.mark.gpu
 
@@ -473,3 +501,38 @@ def test_first_streamed_chunk_leaves_long_before_the_whole_waveform(dims):
     assert len(head) == 2 * 64 * 512
     assert head + rest == pcm.tobytes()                  # byte-identical to the one-shot waveform
     assert min(firsts[1:]) < 0.6 * min(wholes[1:]), (firsts, wholes)
+
+
+@gpu
+def test_pooled_service_slots_deliver_the_single_service_audio(dims):
+    """Two slots on two streams, driven from two threads at once: each request's PCM16 equals the one-context service's
+    (same kernels, same inputs), streamed chunks included."""
+    from vispeech_amd.pipeline import InFlightPool
+    from vispeech_amd.service import PooledSynthesisService, SynthesisService
+    from vispeech_amd.synth import synth_batch, synth_state_dict
+    sd = synth_state_dict(dims, seed=1234, infer_only=True)
+    pool = InFlightPool(make_net, lambda m: m.load_state_dict(sd), n=2)
+    svc = PooledSynthesisService(pool, chunk_frames=32)
+    one = SynthesisService(pool.nets[0], chunk_frames=32)
+    batches = [synth_batch(2, seed=40 + i, mean_phonemes=12, std_phonemes=2, min_phonemes=8, max_phonemes=16, mean_frames=90,
+                           jitter_frames=30) for i in range(4)]
+    noises = [torch.from_numpy(b["noise"]).to(pool.nets[0].device) for b in batches]
+    ref = [one.synthesize(b, 1, noise=n) for b, n in zip(batches, noises)]
+    got = [None] * 4
+
+    def work(k):
+        r = None
+        while r is None:                       # (a refused request is retried: only two slots)
+            r = svc.synthesize(batches[k], 1, noise=noises[k])
+        got[k] = r
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(60)
+    for k in range(4):
+        np.testing.assert_array_equal(got[k], ref[k])
+    streamed = b"".join(svc.stream(batches[0], 1, noise=noises[0]))
+    assert streamed == ref[0].tobytes()
+    assert not svc.busy
