@@ -178,6 +178,34 @@ def test_service_is_single_flight_and_never_queues():
         assert (w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()) == (1, 2, 44100, 12)
 
 
+def test_in_flight_pool_host_logic_with_one_context():
+    """vispeech_amd.pipeline.InFlightPool without a GPU: one context = the caller's stream, no event; the loader runs once
+    per context that the pool builds itself; `after` sees the result; n < 1 is refused."""
+    from vispeech_amd.pipeline import InFlightPool
+    built, loaded, seen = [], [], []
+
+    class Net:
+        device = "cpu"
+
+        def infer(self, x, k=0):
+            return (x + k,)
+
+    def make():
+        built.append(1)
+        return Net()
+
+    pool = InFlightPool(make, lambda m: loaded.append(m), n=1)
+    assert len(pool) == 1 and pool.streams == [None] and len(built) == 1 and loaded == pool.nets
+    res, ev = pool.infer(2, k=3, after=lambda r: seen.append(r))
+    assert res == (5,) and ev is None and seen == [(5,)]
+    first = Net()
+    pool2 = InFlightPool(make, lambda m: loaded.append(m), n=1, first=first)      # a ready-made first context is adopted as is
+    assert pool2.nets == [first] and len(built) == 1
+    assert pool.restrict(1).nets == pool.nets
+    with pytest.raises(ValueError):
+        InFlightPool(make, lambda m: None, n=0)
+
+
 def test_pooled_service_serves_n_requests_and_refuses_the_next():
     """Round 6: N single-flight slots (one per context of an InFlightPool) -- the reference's "refuse, never queue" with N
     locks instead of one (inference_api.py:13, 37): two requests run side by side, the third is refused at once, a freed

@@ -34,9 +34,9 @@ class InFlightPool:
             m = make_net()
             load(m)
             self.nets.append(m)
-        dev = self.nets[0].device
         # one context runs on the caller's current stream (no stream switch at all: the single-batch form)
-        self.streams: List[Optional[torch.cuda.Stream]] = [None] if n == 1 else [torch.cuda.Stream(dev) for _ in self.nets]
+        self.streams: List[Optional[torch.cuda.Stream]] = \
+            [None] if n == 1 else [torch.cuda.Stream(self.nets[0].device) for _ in self.nets]
         self._k = 0
 
     def __len__(self) -> int:
@@ -57,8 +57,10 @@ class InFlightPool:
             res = net.infer(*args, **kwargs)
             if after is not None:
                 after(res)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(net.device))
+            ev = None
+            if str(getattr(net, "device", "")).startswith("cuda"):
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(net.device))
             return res, ev
         # inputs produced on the caller's stream must be complete before this context's stream reads them -- and their
         # memory must not be handed to a later allocation on the caller's stream while this one still reads it
