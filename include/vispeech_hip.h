@@ -35,7 +35,9 @@ extern "C" {
 /* 7 (round 6): (a) vsp_status -- sticky numeric-range flags raised by the kernels (see there); (b) the generator's
  * activations are carried * 2^VSP_ACT_SCALE_LOG2 between conv_pre and conv_post and the packed generator biases carry that
  * factor: an arena packed by an ABI-6 library (or under another VSP_ACT_SCALE_LOG2: the arena's configuration hash covers it)
- * must not be adopted. */
+ * must not be adopted; (c) vsp_profile_read_class / vsp_profile_read_families return one more figure per class / family, the
+ * bytes a launch moves AS FUSED (a new trailing out-parameter each: callers of ABI <= 6 must be rebuilt); (d) vsp_conv1d
+ * accepts split_f16 = 2 (the column-tile kernel as a stand-alone operator). */
 #define VSP_ABI_VERSION 7
 
 enum {
